@@ -1,0 +1,138 @@
+"""Pin oracle/audio_oracle.py against the committed golden fixtures (CPU only).
+
+Tolerances are the reference's own: stft rtol=atol=1e-4, windows
+1e-5, filterbank 1e-5, DCT 1e-4, resample 1e-4.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import audio_oracle as ao
+
+
+def _meta(z):
+    for row in z["meta"]:
+        yield str(row).split(",")
+
+
+def test_stft_matches_torch():
+    z = load_golden("stft_torch.npz")
+    for name, n_fft, hop, wl, center, pad_mode, window in _meta(z):
+        S = ao.stft(z[f"{name}_y"], n_fft=int(n_fft), hop_length=int(hop),
+                    win_length=int(wl), window=window, center=bool(int(center)),
+                    pad_mode=pad_mode)
+        np.testing.assert_allclose(S, z[f"{name}_S"], rtol=1e-4, atol=1e-4, err_msg=name)
+
+
+def test_istft_matches_torch():
+    z = load_golden("stft_torch.npz")
+    for name, n_fft, hop, wl, center, pad_mode, window in _meta(z):
+        if not int(center):
+            continue
+        y = ao.istft(z[f"{name}_S"], hop_length=int(hop), win_length=int(wl),
+                     n_fft=int(n_fft), window=window, center=True,
+                     length=z[f"{name}_y"].shape[-1])
+        ref = z[f"{name}_istft"]
+        # torch.istft divides by sum(w^2) without the 1e-8 floor; interior samples agree.
+        n = int(n_fft)
+        np.testing.assert_allclose(y[..., n:-n], ref[..., n:-n], rtol=1e-4, atol=1e-4, err_msg=name)
+
+
+def test_round_trip_1e5():
+    # README.md:118 — max|y - istft(stft(y))| < 1e-5 for COLA windows
+    y = ao.random_signal(22050)
+    for n_fft, hop in ((2048, 512), (1024, 256), (512, 128)):
+        S = ao.stft(y, n_fft=n_fft, hop_length=hop)
+        yr = ao.istft(S, hop_length=hop, length=len(y))
+        assert np.max(np.abs(y - yr)) < 1e-5
+
+
+@pytest.mark.parametrize("native", [True, False])
+def test_windows_match_scipy(native):
+    z = load_golden("windows_scipy.npz")
+    for key in z.files:
+        name, n, periodic = key.rsplit("_", 2)
+        w = ao.get_window(name, int(n), fftbins=bool(int(periodic)), native=native)
+        np.testing.assert_allclose(w, z[key], rtol=1e-5, atol=1e-5, err_msg=key)
+
+
+def test_window_symmetry_exact():
+    # tests/test_mathematical_properties.py:619-634 — symmetric windows are
+    # symmetric to the last bit.
+    for name in ("hann", "hamming", "blackman", "bartlett"):
+        for n in (16, 255, 512, 2048):
+            w = ao.get_window(name, n, fftbins=False, native=True)
+            assert np.array_equal(w, w[::-1]), (name, n)
+
+
+def test_mel_filterbank_matches_librosa_standin():
+    z = load_golden("mel_filters.npz")
+    for name, sr, n_fft, n_mels, fmin, fmax, norm, scale in _meta(z):
+        norm = None if norm == "None" else norm
+        for fn in (ao.mel_filterbank, ao.mel_filterbank_native):
+            fb = fn(int(sr), int(n_fft), int(n_mels), float(fmin), float(fmax),
+                    htk=(scale == "htk"), norm=norm)
+            np.testing.assert_allclose(fb, z[name], rtol=1e-5, atol=1e-5, err_msg=name)
+
+
+def test_mel_scale_known_answers():
+    z = load_golden("mel_filters.npz")
+    np.testing.assert_allclose(ao.hz_to_mel(z["htk_hz"], htk=True), z["htk_mel"], rtol=1e-12)
+    np.testing.assert_allclose(ao.mel_to_hz(z["htk_mel"], htk=True), z["htk_hz"], atol=1e-9)
+    np.testing.assert_allclose(ao.hz_to_mel(z["slaney_hz"]), z["slaney_mel"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ao.mel_to_hz(z["slaney_mel"]), z["slaney_hz"], rtol=1e-12, atol=1e-9)
+
+
+def test_filterbank_coverage():
+    # tests/test_mathematical_properties.py:484-499 — at most 3 filters per bin
+    fb = ao.mel_filterbank(22050, 2048, 128)
+    assert ((fb > 0).sum(axis=0) <= 3).all()
+    with pytest.raises(ValueError, match="cannot exceed Nyquist"):
+        ao.mel_filterbank(22050, 2048, 128, fmax=12000.0)
+
+
+def test_dct_matches_scipy():
+    z = load_golden("dct_scipy.npz")
+    np.testing.assert_allclose(ao.dct(z["x"]), z["ortho_full"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ao.dct(z["x"], n=13), z["ortho_13"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ao.dct(z["x"], norm=None), z["none_full_half_scipy"], rtol=1e-4, atol=1e-4)
+
+
+def test_pad_known_answers():
+    z = load_golden("kats.npz")
+    for mode in ("reflect", "constant", "edge"):
+        np.testing.assert_array_equal(ao.pad_signal(z["pad_in"], 3, mode), z[f"pad_{mode}_3"])
+
+
+def test_resample_poly_restatement_matches_scipy():
+    z = load_golden("resample_scipy.npz")
+    for tag, up, down in (("p13", 1, 3), ("p21", 2, 1), ("p32", 3, 2), ("p147_160", 147, 160)):
+        got = ao.resample_poly_restated(z[f"{tag}_y"], up, down)
+        assert got.shape == z[f"{tag}_out"].shape
+        np.testing.assert_allclose(got, z[f"{tag}_out"], rtol=1e-5, atol=2e-6, err_msg=tag)
+        np.testing.assert_array_equal(ao.resample_poly(z[f"{tag}_y"], up, down), z[f"{tag}_out"])
+
+
+def test_frame_and_shapes():
+    y = np.arange(100, dtype=np.float32)
+    fr = ao.frame_signal(y, 10, 5)
+    assert fr.shape == (19, 10)
+    assert fr[3, 2] == 17
+    S = ao.stft(np.zeros(22050, np.float32), n_fft=2048, hop_length=512)
+    assert S.shape == (1025, 44) and S.dtype == np.complex64
+    with pytest.raises(ValueError, match="must be positive"):
+        ao.stft(y, hop_length=0)
+
+
+def test_griffinlim_reference_thresholds():
+    # tests/test_griffinlim.py:99-121 — MSE of |stft(griffinlim(S))| vs S on the chirp
+    y = ao.chirp_signal()[:8192]
+    S = ao.magnitude(ao.stft(y, n_fft=512, hop_length=128))
+    yr = ao.griffinlim(S, n_iter=16, hop_length=128, random_state=42, length=len(y))
+    Sr = ao.magnitude(ao.stft(yr, n_fft=512, hop_length=128))
+    assert np.mean((S - Sr) ** 2) < 10.0
+    yr2 = ao.griffinlim(S, n_iter=16, hop_length=128, random_state=42, length=len(y))
+    np.testing.assert_allclose(yr, yr2, atol=1e-5)
+    with pytest.raises(ValueError, match="Unknown init"):
+        ao.griffinlim(S, init="bogus")
