@@ -1,0 +1,165 @@
+/*
+ * audioprims.h — C ABI of libaudioprims_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary that takes the place of the reference's native
+ * extension (nanobind module `_ext`, /root/reference/csrc/bindings.cpp:11-485)
+ * and of the two third-party device calls on the hot path that have no source
+ * under the reference (`mx.fft.rfft`, stft.py:130; `mx.fft.irfft`, stft.py:295).
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures.  `stream` is a hipStream_t
+ *    passed as void* (NULL = the default stream).
+ *  - every pointer marked [dev] is device memory owned and pre-allocated by the
+ *    caller; [host] is host memory.  The library never allocates or frees device
+ *    memory, never synchronises: it only enqueues kernels on `stream`
+ *    (the reference's Metal paths force eval() before encoding,
+ *    overlap_add.cpp:45-48 — not reproduced).
+ *  - all arrays are contiguous float32 (complex = interleaved re,im float32),
+ *    row-major, shapes as in the reference's Python API.
+ *  - return value: 0 = ok; AP_ERR_INVALID (<0) = invalid argument (the
+ *    reference throws std::invalid_argument -> Python ValueError, e.g.
+ *    overlap_add.cpp:205-222); AP_ERR_UNSUPPORTED; AP_ERR_HIP = a HIP runtime
+ *    error at launch.  ap_last_error() returns a thread-local message.
+ *  - re-entrant, no hidden state: windows, filterbanks, twiddles and FIR taps
+ *    are inputs (built on the host in float64 by the ap_*_host builders below,
+ *    cached per device by the caller).
+ */
+#ifndef AUDIOPRIMS_H
+#define AUDIOPRIMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AP_OK 0
+#define AP_ERR_INVALID (-1)
+#define AP_ERR_UNSUPPORTED (-2)
+#define AP_ERR_HIP (-3)
+
+/* pad modes — stft.py:441-468, pad_signal.metal:10-121 */
+#define AP_PAD_CONSTANT 0
+#define AP_PAD_EDGE 1
+#define AP_PAD_REFLECT 2
+
+/* window kinds — windows.cpp:179-228 */
+#define AP_WIN_HANN 0
+#define AP_WIN_HAMMING 1
+#define AP_WIN_BLACKMAN 2
+#define AP_WIN_BARTLETT 3
+#define AP_WIN_RECTANGULAR 4
+
+int ap_version(void);
+const char *ap_last_error(void);
+
+/* ---------------------------------------------------------------------- *
+ * Host-side builders (float64 internally).  Replace the CPU-stream parts of
+ * the reference extension.
+ * ---------------------------------------------------------------------- */
+
+/* generate_window(window_type, length, periodic) — bindings.cpp:105-130,
+ * windows.cpp:179-228: float64 build, cast to float32, average with own
+ * reverse (windows.cpp:73-78); periodic = (length+1)-point window minus the
+ * last point.  out_host: `length` floats. */
+int ap_generate_window_host(int kind, int length, int periodic, float *out_host);
+
+/* hz_to_mel / mel_to_hz(arr, htk) — bindings.cpp:133-181, mel_filterbank.cpp:70-106.
+ * float64 in/out on the host. */
+int ap_hz_to_mel_host(const double *hz, int64_t n, int htk, double *out);
+int ap_mel_to_hz_host(const double *mel, int64_t n, int htk, double *out);
+
+/* mel_filterbank(sr, n_fft, n_mels, fmin, fmax, htk, norm) — bindings.cpp:183-221,
+ * mel_filterbank.cpp:108-239 (librosa's fdiff/ramps formulation, float64, one cast).
+ * fmax < 0 means sr/2.  norm_slaney: 1 = "slaney", 0 = none.
+ * out_host: n_mels*(n_fft/2+1) floats. */
+int ap_mel_filterbank_host(int sr, int n_fft, int n_mels, double fmin, double fmax,
+                           int htk, int norm_slaney, float *out_host);
+
+/* get_dct_matrix(n_out, n_in, norm) — bindings.cpp:313-335, dct.cpp:24-101:
+ * DCT-II basis evaluated in FLOAT32 like the reference's native path (dct.cpp:59).
+ * out_host: n_out*n_in floats. */
+int ap_dct_matrix_host(int n_out, int n_in, int ortho, float *out_host);
+
+/* Twiddle table for an n_fft-point real transform: out_host[2j] = cos(2*pi*j/n),
+ * out_host[2j+1] = sin(2*pi*j/n), j in [0,n), float64-evaluated, exact at the
+ * quadrant points.  (Stands in for whatever mx.fft precomputes internally.) */
+int ap_twiddle_table_host(int n_fft, float *out_host);
+
+/* 1 if the LDS FFT engine can transform n_fft-point real frames, else 0. */
+int ap_fft_supported(int n_fft);
+
+/* ---------------------------------------------------------------------- *
+ * Device primitives — 1:1 with the reference extension's hot-path entries.
+ * ---------------------------------------------------------------------- */
+
+/* pad_signal(signal (B,L), pad_length, mode) -> (B, L+2*pad) — bindings.cpp:76-102,
+ * pad_signal.cpp:133-162.  reflect requires pad <= L-1 (pad_signal.cpp:102-105). */
+int ap_pad_f32(const float *x /*dev*/, int64_t B, int64_t L, int64_t pad, int mode,
+               float *out /*dev (B, L+2*pad)*/, void *stream);
+
+/* frame_signal(signal (B,L), frame_length, hop) -> (B,T,frame_length),
+ * T = 1 + (L-frame_length)/hop — bindings.cpp:48-74, frame_signal.cpp:119-155. */
+int ap_frame_f32(const float *x /*dev*/, int64_t B, int64_t L, int frame_length, int hop,
+                 float *out /*dev (B,T,frame_length)*/, void *stream);
+
+/* overlap_add(frames (B,T,N), window (N,), hop, output_length) -> (B,out_len)
+ * — bindings.cpp:15-46, overlap_add.cpp:195-233, overlap_add.metal:16-55:
+ *   out[b,i] = sum_f w[p-fH]*frames[b,f,p-fH] / max(sum_f w[p-fH]^2, 1e-8),  p = i + out_offset
+ * `out_offset` (>=0) lets istft fold its centre trim (stft.py:315-329) into the
+ * same pass; the reference entry is out_offset = 0. */
+int ap_overlap_add_f32(const float *frames /*dev*/, const float *window /*dev*/, int64_t B,
+                       int64_t T, int n_fft, int hop, int64_t out_offset, int64_t out_len,
+                       float *out /*dev (B,out_len)*/, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Fused transforms — replace `_stft_core` (pad -> frame -> *window -> mx.fft.rfft,
+ * stft.py:109-133) plus the transpose (stft.py:216), and mel.py:310-350.
+ * ---------------------------------------------------------------------- */
+
+/* stft: y (B,L) -> out (B, F=n_fft/2+1, T) complex64 (interleaved).
+ *   window : n_fft floats, already centre-padded (stft.py:88-106)
+ *   tw     : table from ap_twiddle_table_host(n_fft) copied to the device
+ *   center : pad n_fft/2 both sides with `pad_mode` without materialising it
+ *   T must equal 1 + (L + 2*pad - n_fft)/hop (_frame_impl.py:61). */
+int ap_stft_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop,
+                const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
+                int64_t T, float *out /*dev (B,F,T,2)*/, void *stream);
+
+/* melspectrogram: y (B,L) -> out (B, n_mels, T) = fb @ |stft(y)|^power, fused
+ * (no (B,F,T) intermediate).  fb is the dense (n_mels, F) filterbank
+ * (mel.py:100-168); band_lo/band_len (n_mels int32 each, may be NULL = dense)
+ * give, per filter, the first bin and count of the span holding all its
+ * non-zeros — zeros outside the span contribute exactly 0 to the reference's
+ * matmul (mel.py:344-350), so skipping them does not change the result. */
+int ap_melspec_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop,
+                   const float *window /*dev*/, const float *tw /*dev*/, int center,
+                   int pad_mode, int64_t T, const float *fb /*dev (M,F)*/,
+                   const int32_t *band_lo /*dev*/, const int32_t *band_len /*dev*/,
+                   int n_mels, float power, float *out /*dev (B,M,T)*/, void *stream);
+
+/* irfft of every frame: S (B,F,T) complex64 -> frames (B,T,n_fft) float32,
+ * 1/n_fft scaled; imaginary parts of the DC and Nyquist bins are ignored —
+ * mx.fft.irfft(·, n=n_fft) at stft.py:292-295 (incl. the transpose). */
+int ap_irfft_frames_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, int n_fft,
+                        const float *tw /*dev*/, float *frames /*dev (B,T,n_fft)*/,
+                        void *stream);
+
+/* istft core: irfft + window + overlap-add + sum(w^2) normalise + trim.
+ *   out[b,i] = OLA(position i + out_offset), i in [0,out_len)
+ *   frames_ws : caller-provided workspace of B*T*n_fft floats.
+ * Length logic (stft.py:300-338) stays in the caller. */
+int ap_istft_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, int n_fft, int hop,
+                 const float *window /*dev*/, const float *tw /*dev*/, float *frames_ws /*dev*/,
+                 int64_t out_offset, int64_t out_len, float *out /*dev (B,out_len)*/,
+                 void *stream);
+
+/* magnitude / phase / |S|^p of a complex64 array of n elements —
+ * stft.py:347-379 (mx.abs, mx.arctan2). */
+int ap_magnitude_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);
+int ap_phase_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOPRIMS_H */

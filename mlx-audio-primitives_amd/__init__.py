@@ -1,0 +1,22 @@
+"""MI355X-native audio-DSP primitives with the librosa-compatible API of
+zkeown/mlx-audio-primitives for its feature-extraction hot path.
+
+Tensors are torch tensors in HBM; every device op is a hand-written gfx950 HIP
+kernel behind the C ABI in include/audioprims.h.  There is no CPU fallback.
+"""
+
+from ._extension import HAS_HIP_EXT, _ext
+from ._validation import validate_non_negative, validate_positive, validate_range
+from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
+from .stft import check_nola, istft, magnitude, phase, stft
+from .windows import get_window
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "HAS_HIP_EXT", "_ext",
+    "stft", "istft", "magnitude", "phase", "check_nola",
+    "get_window",
+    "hz_to_mel", "mel_to_hz", "mel_filterbank", "melspectrogram",
+    "validate_positive", "validate_non_negative", "validate_range",
+]

@@ -1,0 +1,321 @@
+"""The drop-in boundary: loads libaudioprims_hip.so (C ABI, include/audioprims.h) and
+publishes ``HAS_HIP_EXT`` / ``_ext`` the way the reference publishes
+``HAS_CPP_EXT`` / ``_ext`` (/root/reference/mlx_audio_primitives/_extension.py:25-44).
+
+Differences from the reference, on purpose:
+  * there is NO framework fallback.  The reference silently degrades to an MLX op
+    graph when its extension is missing; here every device op raises
+    ``RuntimeError`` if the HIP library or a GPU is missing, so a silent slow path
+    can never be mistaken for the product.
+  * ``_ext`` is a thin Python object over ctypes whose methods have the reference
+    nanobind signatures (csrc/bindings.cpp:15-368) but take/return torch tensors
+    living in HBM.  PyTorch only supplies device memory and the current stream.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Any
+
+import numpy as np
+
+from . import _build
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+PAD_MODES = {"constant": 0, "edge": 1, "reflect": 2}
+WINDOW_KINDS = {
+    "hann": 0, "hanning": 0, "hamming": 1, "blackman": 2, "bartlett": 3, "triangular": 3,
+    "rectangular": 4, "boxcar": 4, "ones": 4,
+}
+
+#: every symbol include/audioprims.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ap_version", "ap_last_error",
+    "ap_generate_window_host", "ap_hz_to_mel_host", "ap_mel_to_hz_host",
+    "ap_mel_filterbank_host", "ap_dct_matrix_host", "ap_twiddle_table_host", "ap_fft_supported",
+    "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
+    "ap_stft_f32", "ap_melspec_f32", "ap_irfft_frames_f32", "ap_istft_f32",
+    "ap_magnitude_f32", "ap_phase_f32",
+]
+
+HAS_HIP_EXT: bool = False
+_lib: Any | None = None
+_load_error: str | None = None
+
+
+def _declare(lib) -> None:
+    P, I, L, F = ctypes.c_void_p, _int, _i64, ctypes.c_float
+    lib.ap_version.restype = I
+    lib.ap_last_error.restype = ctypes.c_char_p
+    sig = {
+        "ap_generate_window_host": [I, I, I, P],
+        "ap_hz_to_mel_host": [P, L, I, P],
+        "ap_mel_to_hz_host": [P, L, I, P],
+        "ap_mel_filterbank_host": [I, I, I, ctypes.c_double, ctypes.c_double, I, I, P],
+        "ap_dct_matrix_host": [I, I, I, P],
+        "ap_twiddle_table_host": [I, P],
+        "ap_fft_supported": [I],
+        "ap_pad_f32": [P, L, L, L, I, P, P],
+        "ap_frame_f32": [P, L, L, I, I, P, P],
+        "ap_overlap_add_f32": [P, P, L, L, I, I, L, L, P, P],
+        "ap_stft_f32": [P, L, L, I, I, P, P, I, I, L, P, P],
+        "ap_melspec_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P],
+        "ap_irfft_frames_f32": [P, L, L, I, P, P, P],
+        "ap_istft_f32": [P, L, L, I, I, P, P, P, L, L, P, P],
+        "ap_magnitude_f32": [P, L, P, P],
+        "ap_phase_f32": [P, L, P, P],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = I
+
+
+def _load() -> None:
+    global HAS_HIP_EXT, _lib, _load_error
+    path = _build.LIB_PATH
+    try:
+        if not os.path.exists(path):
+            raise OSError(f"{path} not built (run __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        _declare(lib)
+        # smoke-test one host entry, as the reference does with generate_window("hann", 4, True)
+        buf = (ctypes.c_float * 4)()
+        if lib.ap_generate_window_host(0, 4, 1, ctypes.cast(buf, ctypes.c_void_p)) != 0:
+            raise OSError("ap_generate_window_host smoke test failed")
+        _lib = lib
+        HAS_HIP_EXT = True
+        _load_error = None
+    except (OSError, AttributeError) as e:
+        _lib = None
+        HAS_HIP_EXT = False
+        _load_error = str(e)
+
+
+_load()
+
+
+def lib():
+    """The raw ctypes handle; raises loudly when the HIP extension is missing."""
+    if _lib is None:
+        raise RuntimeError(
+            "libaudioprims_hip.so is not available: "
+            f"{_load_error}. There is no CPU/framework fallback on purpose."
+        )
+    return _lib
+
+
+def check(rc: int) -> None:
+    """Turn a C status into the exception the reference would raise."""
+    if rc == 0:
+        return
+    msg = lib().ap_last_error().decode()
+    if rc in (-1, -2):
+        raise ValueError(msg)       # std::invalid_argument -> ValueError in the reference
+    raise RuntimeError(msg)
+
+
+def require_device(device=None):
+    """Resolve the HIP device to run on; no GPU is a hard error."""
+    import torch
+
+    lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "no HIP device visible: the audio primitives run only on a GPU "
+            "(there is no CPU fallback)."
+        )
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"expected a HIP ('cuda') device, got {device}")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def to_device_f32(x, device=None):
+    """Contiguous float32 tensor in HBM (mirrors astype(float32)+contiguous at
+    overlap_add.cpp:27-34)."""
+    import torch
+
+    if isinstance(x, torch.Tensor):
+        if x.is_cuda and device is None:
+            dev = x.device
+        else:
+            dev = require_device(device)
+        lib()
+        return x.to(device=dev, dtype=torch.float32).contiguous()
+    dev = require_device(device)
+    return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev).contiguous()
+
+
+def stream_ptr(device) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t) -> int:
+    return t.data_ptr()
+
+
+# --------------------------------------------------------------------------
+# host builders (work without a GPU: pure host code inside the .so)
+# --------------------------------------------------------------------------
+def generate_window_host(window_type: str, length: int, periodic: bool = True) -> np.ndarray:
+    kind = WINDOW_KINDS.get(window_type)
+    if kind is None:
+        raise ValueError(
+            f"Unknown window type: '{window_type}'. "
+            "Supported: hann, hamming, blackman, bartlett, rectangular"
+        )
+    if length <= 0:
+        raise ValueError("Window length must be positive")
+    out = np.empty(length, np.float32)
+    check(lib().ap_generate_window_host(kind, int(length), int(bool(periodic)), out.ctypes.data))
+    return out
+
+
+def twiddle_table_host(n_fft: int) -> np.ndarray:
+    out = np.empty(2 * n_fft, np.float32)
+    check(lib().ap_twiddle_table_host(int(n_fft), out.ctypes.data))
+    return out
+
+
+def mel_filterbank_host(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False,
+                        norm="slaney") -> np.ndarray:
+    if norm not in ("slaney", "", None):
+        raise ValueError(f"Unknown norm: '{norm}'. Supported: 'slaney', empty string for none")
+    out = np.empty((max(int(n_mels), 0), 1 + max(int(n_fft), 0) // 2), np.float32)
+    check(lib().ap_mel_filterbank_host(int(sr), int(n_fft), int(n_mels), float(fmin),
+                                       -1.0 if fmax is None else float(fmax), int(bool(htk)),
+                                       1 if norm == "slaney" else 0, out.ctypes.data))
+    return out
+
+
+def dct_matrix_host(n_out: int, n_in: int, norm: str | None = "ortho") -> np.ndarray:
+    out = np.empty((n_out, n_in), np.float32)
+    check(lib().ap_dct_matrix_host(int(n_out), int(n_in), 1 if norm == "ortho" else 0,
+                                   out.ctypes.data))
+    return out
+
+
+def _mel_scale_host(fn_name: str, arr, htk: bool) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64))
+    out = np.empty_like(a)
+    check(getattr(lib(), fn_name)(a.ctypes.data, a.size, int(bool(htk)), out.ctypes.data))
+    return out
+
+
+# --------------------------------------------------------------------------
+# `_ext`: the reference extension's Python-visible surface (bindings.cpp:15-368)
+# --------------------------------------------------------------------------
+class _Ext:
+    """Same entry points, argument order and defaults as the reference's nanobind
+    module; tensors are torch tensors in HBM; `stream` = a torch.cuda.Stream or None."""
+
+    @staticmethod
+    def _stream(stream, device):
+        return stream.cuda_stream if stream is not None else stream_ptr(device)
+
+    def overlap_add(self, frames, window, hop_length, output_length, stream=None):
+        import torch
+
+        frames = to_device_f32(frames)
+        if frames.ndim != 3:
+            raise ValueError("frames must be 3D (batch, n_frames, n_fft)")
+        window = to_device_f32(window, frames.device)
+        if window.ndim != 1:
+            raise ValueError("window must be 1D")
+        B, T, N = frames.shape
+        if window.shape[0] != N:
+            raise ValueError("Window length must match frame length (n_fft)")
+        if hop_length <= 0:
+            raise ValueError("hop_length must be positive")
+        if output_length <= 0:
+            raise ValueError("output_length must be positive")
+        out = torch.empty((B, output_length), dtype=torch.float32, device=frames.device)
+        check(lib().ap_overlap_add_f32(ptr(frames), ptr(window), B, T, N, int(hop_length), 0,
+                                       int(output_length), ptr(out),
+                                       self._stream(stream, frames.device)))
+        return out
+
+    def frame_signal(self, signal, frame_length, hop_length, stream=None):
+        import torch
+
+        signal = to_device_f32(signal)
+        one_d = signal.ndim == 1
+        if one_d:
+            signal = signal[None, :]
+        if signal.ndim != 2:
+            raise ValueError("signal must be 1D or 2D")
+        B, L = signal.shape
+        if frame_length <= 0:
+            raise ValueError("frame_length must be positive")
+        if hop_length <= 0:
+            raise ValueError("hop_length must be positive")
+        if L < frame_length:
+            raise ValueError(
+                f"Signal length ({L}) must be >= frame_length ({frame_length}). "
+                f"Consider padding the signal."
+            )
+        T = 1 + (L - frame_length) // hop_length
+        out = torch.empty((B, T, frame_length), dtype=torch.float32, device=signal.device)
+        check(lib().ap_frame_f32(ptr(signal), B, L, int(frame_length), int(hop_length), ptr(out),
+                                 self._stream(stream, signal.device)))
+        return out[0] if one_d else out
+
+    def pad_signal(self, signal, pad_length, mode="constant", stream=None):
+        import torch
+
+        signal = to_device_f32(signal)
+        if signal.ndim != 2:
+            raise ValueError("signal must be 2D (batch, samples)")
+        if mode not in PAD_MODES:
+            raise ValueError(f"Unknown pad mode: '{mode}'. Supported: constant, edge, reflect")
+        if pad_length < 0:
+            raise ValueError("pad_length must be non-negative")
+        if pad_length == 0:
+            return signal                                      # pad_signal.cpp:149-151
+        B, L = signal.shape
+        out = torch.empty((B, L + 2 * pad_length), dtype=torch.float32, device=signal.device)
+        check(lib().ap_pad_f32(ptr(signal), B, L, int(pad_length), PAD_MODES[mode], ptr(out),
+                               self._stream(stream, signal.device)))
+        return out
+
+    def generate_window(self, window_type, length, periodic=True, stream=None):
+        import torch
+
+        w = generate_window_host(window_type, length, periodic)
+        t = torch.from_numpy(w)
+        return t.to(require_device()) if torch.cuda.is_available() else t
+
+    def hz_to_mel(self, frequencies, htk=False, stream=None):
+        return _mel_scale_host("ap_hz_to_mel_host", frequencies, htk).astype(np.float32)
+
+    def mel_to_hz(self, mels, htk=False, stream=None):
+        return _mel_scale_host("ap_mel_to_hz_host", mels, htk).astype(np.float32)
+
+    def mel_filterbank(self, sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False,
+                       norm="slaney", stream=None):
+        import torch
+
+        t = torch.from_numpy(mel_filterbank_host(sr, n_fft, n_mels, fmin, fmax, htk, norm))
+        return t.to(require_device()) if torch.cuda.is_available() else t
+
+    def get_dct_matrix(self, n_out, n_in, norm="ortho", stream=None):
+        import torch
+
+        t = torch.from_numpy(dct_matrix_host(n_out, n_in, norm))
+        return t.to(require_device()) if torch.cuda.is_available() else t
+
+
+_ext: _Ext | None = _Ext() if HAS_HIP_EXT else None
+
+__all__ = ["_ext", "HAS_HIP_EXT", "lib", "check"]

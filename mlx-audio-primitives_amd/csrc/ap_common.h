@@ -1,0 +1,127 @@
+// Shared plain-C++ definitions: kernel parameter blocks, the FFT plan and launch
+// geometry.  Included by the HIP translation unit and by the CPU test emulator
+// (tests/emu), so nothing here may depend on the HIP runtime.
+#pragma once
+#include <stdint.h>
+
+#define AP_MAX_PASSES 16
+#define AP_BLOCK 256               // threads per workgroup of the LDS engine (4 wave64)
+#define AP_LDS_TILE_BUDGET (64 * 1024)   // target LDS per workgroup when batching frames
+#define AP_LDS_MAX (160 * 1024)    // gfx950 LDS per CU / max per workgroup
+#define AP_MAX_G 16                // max frames per workgroup tile
+
+struct __attribute__((aligned(8))) ap_float2 {
+    float x, y;
+};
+
+// Radix plan of the complex transform that backs an n_fft-point real transform.
+//   even n_fft : nc = n_fft/2 complex points (pack x[2n] + i x[2n+1]) + split pass
+//   odd  n_fft : nc = n_fft complex points with zero imaginary part
+struct ApFftPlan {
+    int n;        // n_fft
+    int nc;       // complex length
+    int even;     // 1 if n even
+    int tw_step;  // table stride turning W_nc^m into the W_n table index (2 if even else 1)
+    int n_pass;
+    int radix[AP_MAX_PASSES];
+};
+
+// Factor nc into radices this engine has in-register butterflies for (16,8,4,2,5,3)
+// plus arbitrary primes (handled by the O(p) per-output generic pass).
+static inline int ap_make_plan(int n_fft, ApFftPlan *p) {
+    if (n_fft < 1) return -1;
+    p->n = n_fft;
+    p->even = (n_fft % 2 == 0) ? 1 : 0;
+    p->nc = p->even ? n_fft / 2 : n_fft;
+    p->tw_step = p->even ? 2 : 1;
+    p->n_pass = 0;
+    int m = p->nc;
+    // powers of two: prefer 16s and 8s, finish with 4 / 2
+    int e2 = 0;
+    while (m % 2 == 0) { m /= 2; e2++; }
+    while (e2 >= 4 && e2 != 5) { p->radix[p->n_pass++] = 16; e2 -= 4; }   // leave 5 = 8*4
+    while (e2 >= 3) { p->radix[p->n_pass++] = 8; e2 -= 3; }
+    if (e2 == 2) { p->radix[p->n_pass++] = 4; e2 = 0; }
+    if (e2 == 1) { p->radix[p->n_pass++] = 2; e2 = 0; }
+    while (m % 5 == 0) { p->radix[p->n_pass++] = 5; m /= 5; }
+    while (m % 3 == 0) { p->radix[p->n_pass++] = 3; m /= 3; }
+    for (int f = 7; (int64_t)f * f <= m; f += 2) {
+        while (m % f == 0) {
+            if (p->n_pass >= AP_MAX_PASSES) return -1;
+            p->radix[p->n_pass++] = f;
+            m /= f;
+        }
+    }
+    if (m > 1) {
+        if (p->n_pass >= AP_MAX_PASSES) return -1;
+        p->radix[p->n_pass++] = m;
+    }
+    if (p->n_pass > AP_MAX_PASSES) return -1;
+    return 0;
+}
+
+// LDS geometry of the generic engine: two ping-pong complex buffers per frame,
+// `fstride` float2 per buffer per frame (padded by one to break the power-of-two
+// stride between frames), G frames per workgroup.
+struct ApTile {
+    int G;          // frames per workgroup
+    int fstride;    // float2 elements per frame per buffer
+    int lds_bytes;  // dynamic LDS bytes
+};
+
+static inline int ap_make_tile(const ApFftPlan *p, int64_t T, ApTile *t) {
+    int fstride = p->nc + 1;
+    // the mel epilogue needs nc+1 floats of |X|^p per frame in the idle buffer: fits (2*fstride floats)
+    int64_t per_frame = (int64_t)2 * fstride * (int64_t)sizeof(ap_float2);
+    if (per_frame > AP_LDS_MAX) return -1;
+    int G = (int)(AP_LDS_TILE_BUDGET / per_frame);
+    if (G < 1) G = 1;
+    if (G > AP_MAX_G) G = AP_MAX_G;
+    if ((int64_t)G > T) G = (int)(T > 0 ? T : 1);
+    t->G = G;
+    t->fstride = fstride;
+    t->lds_bytes = (int)(per_frame * G);
+    return 0;
+}
+
+// Parameters of the fused framing + window + real FFT kernel and its epilogues.
+struct ApStftParams {
+    const float *y;        // (B, L)
+    const float *window;   // (n_fft)
+    const ap_float2 *tw;   // (n_fft) (cos, sin)(2 pi j / n_fft)
+    int64_t L;
+    int64_t T;
+    int64_t tiles_per_clip;
+    int hop;
+    int pad;               // left padding in samples (n_fft/2 if center else 0)
+    int pad_mode;
+    int n_bins;            // n_fft/2 + 1
+    ApFftPlan plan;
+    ApTile tile;
+    // epilogue: complex spectrum
+    ap_float2 *out_c;      // (B, F, T)
+    // epilogue: mel
+    float *out_mel;        // (B, M, T)
+    const float *fb;       // (M, F)
+    const int32_t *band_lo;
+    const int32_t *band_len;
+    int n_mels;
+    float power;
+};
+
+struct ApIrfftParams {
+    const ap_float2 *S;    // (B, F, T)
+    const ap_float2 *tw;
+    float *frames;         // (B, T, n_fft)
+    int64_t T;
+    int64_t tiles_per_clip;
+    int n_bins;
+    ApFftPlan plan;
+    ApTile tile;
+};
+
+static inline int64_t ap_n_frames(int64_t L, int n_fft, int hop, int center) {
+    int64_t Lp = L + (center ? 2 * (int64_t)(n_fft / 2) : 0);
+    if (Lp < n_fft) return 0;
+    return 1 + (Lp - n_fft) / hop;
+}

@@ -1,0 +1,147 @@
+// Argument validation and launch geometry for every C-ABI entry point, as plain C++
+// shared by the HIP translation unit (audioprims.hip) and the CPU test emulator
+// (tests/emu).  Validation mirrors the std::invalid_argument checks of the
+// reference extension (overlap_add.cpp:205-222, frame_signal.cpp:128-144,
+// pad_signal.cpp:142-147, _frame_impl.py:51-59).
+#pragma once
+#include <cstdio>
+
+#include "../../include/audioprims.h"
+#include "ap_common.h"
+
+char *ap_error_buffer();            // thread-local, 512 bytes (audioprims.hip / emu)
+
+#define AP_FAIL(code, ...)                                         \
+    do {                                                           \
+        std::snprintf(ap_error_buffer(), 512, __VA_ARGS__);        \
+        return (code);                                             \
+    } while (0)
+
+static const int64_t kApMaxGrid = 2147483647LL;
+static const int64_t kApStreamGrid = 256 * 8;   // memory-bound grid-stride kernels: 8 blocks per CU
+
+static inline int ap_grid_1d(int64_t total, int block, int64_t cap) {
+    int64_t g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+static inline int ap_prepare_pad(const float *x, int64_t B, int64_t L, int64_t pad, int mode,
+                                 const float *out, int *grid) {
+    if (!x || !out) AP_FAIL(AP_ERR_INVALID, "pad_signal: NULL buffer");
+    if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "pad_signal: signal must be non-empty");
+    if (pad < 0) AP_FAIL(AP_ERR_INVALID, "pad_length must be non-negative");
+    if (mode < AP_PAD_CONSTANT || mode > AP_PAD_REFLECT)
+        AP_FAIL(AP_ERR_INVALID, "Unknown pad mode. Supported: constant, edge, reflect");
+    if (mode == AP_PAD_REFLECT && pad > L - 1)
+        AP_FAIL(AP_ERR_INVALID, "reflect padding requires pad_length <= signal_length - 1");
+    *grid = ap_grid_1d(B * (L + 2 * pad), AP_BLOCK, kApStreamGrid);
+    return AP_OK;
+}
+
+static inline int ap_prepare_frame(const float *x, int64_t B, int64_t L, int frame_length, int hop,
+                                   const float *out, int64_t *T, int *grid) {
+    if (!x || !out) AP_FAIL(AP_ERR_INVALID, "frame_signal: NULL buffer");
+    if (frame_length <= 0) AP_FAIL(AP_ERR_INVALID, "frame_length must be positive");
+    if (hop <= 0) AP_FAIL(AP_ERR_INVALID, "hop_length must be positive");
+    if (B <= 0 || L < frame_length)
+        AP_FAIL(AP_ERR_INVALID, "Signal length (%lld) must be >= frame_length (%d)", (long long)L, frame_length);
+    *T = 1 + (L - frame_length) / hop;
+    *grid = ap_grid_1d(B * (*T) * frame_length, AP_BLOCK, kApStreamGrid);
+    return AP_OK;
+}
+
+static inline int ap_prepare_ola(const float *frames, const float *window, int64_t B, int64_t T,
+                                 int n_fft, int hop, int64_t out_offset, int64_t out_len,
+                                 const float *out, int64_t *blocks_per_row) {
+    if (!frames || !window || !out) AP_FAIL(AP_ERR_INVALID, "overlap_add: NULL buffer");
+    if (hop <= 0) AP_FAIL(AP_ERR_INVALID, "hop_length must be positive");
+    if (out_len <= 0) AP_FAIL(AP_ERR_INVALID, "output_length must be positive");
+    if (B <= 0 || T <= 0 || n_fft <= 0)
+        AP_FAIL(AP_ERR_INVALID, "frames must have shape (batch, n_frames, n_fft)");
+    if (out_offset < 0) AP_FAIL(AP_ERR_INVALID, "out_offset must be non-negative");
+    *blocks_per_row = (out_len + AP_BLOCK - 1) / AP_BLOCK;
+    if (*blocks_per_row * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "overlap_add: grid too large");
+    return AP_OK;
+}
+
+static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, int64_t L, int n_fft,
+                                  int hop, const float *window, const float *tw, int center,
+                                  int pad_mode, int64_t T) {
+    if (!y || !window || !tw) AP_FAIL(AP_ERR_INVALID, "stft: NULL buffer");
+    if (n_fft <= 0) AP_FAIL(AP_ERR_INVALID, "n_fft must be positive, got %d", n_fft);
+    if (hop <= 0) AP_FAIL(AP_ERR_INVALID, "hop_length must be positive, got %d", hop);
+    if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "stft: signal must be non-empty");
+    if (pad_mode < AP_PAD_CONSTANT || pad_mode > AP_PAD_REFLECT)
+        AP_FAIL(AP_ERR_INVALID, "Unknown pad_mode. Supported: reflect, constant, edge");
+    const int pad = center ? n_fft / 2 : 0;
+    if (center && pad_mode == AP_PAD_REFLECT && pad > L - 1)
+        AP_FAIL(AP_ERR_INVALID, "reflect padding requires n_fft//2 <= signal_length - 1");
+    const int64_t Texp = ap_n_frames(L, n_fft, hop, center);
+    if (Texp <= 0)
+        AP_FAIL(AP_ERR_INVALID,
+                "Signal length (%lld) must be >= frame_length (%d). Consider padding the signal.",
+                (long long)(L + 2 * pad), n_fft);
+    if (T != Texp)
+        AP_FAIL(AP_ERR_INVALID, "stft: n_frames mismatch (got %lld, expected %lld)", (long long)T,
+                (long long)Texp);
+    if (ap_make_plan(n_fft, &P.plan) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "n_fft=%d: cannot build FFT plan", n_fft);
+    if (ap_make_tile(&P.plan, T, &P.tile) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "n_fft=%d does not fit the %d KiB LDS of one CU", n_fft,
+                AP_LDS_MAX / 1024);
+    P.y = y;
+    P.window = window;
+    P.tw = reinterpret_cast<const ap_float2 *>(tw);
+    P.L = L;
+    P.T = T;
+    P.tiles_per_clip = (T + P.tile.G - 1) / P.tile.G;
+    P.hop = hop;
+    P.pad = pad;
+    P.pad_mode = pad_mode;
+    P.n_bins = n_fft / 2 + 1;
+    P.out_c = nullptr;
+    P.out_mel = nullptr;
+    P.fb = nullptr;
+    P.band_lo = nullptr;
+    P.band_len = nullptr;
+    P.n_mels = 0;
+    P.power = 2.0f;
+    if (P.tiles_per_clip * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "stft: grid too large");
+    return AP_OK;
+}
+
+static inline int ap_prepare_mel(ApStftParams &P, const float *fb, const int32_t *band_lo,
+                                 const int32_t *band_len, int n_mels, float power, float *out) {
+    if (!out || !fb) AP_FAIL(AP_ERR_INVALID, "melspectrogram: NULL buffer");
+    if (n_mels <= 0) AP_FAIL(AP_ERR_INVALID, "n_mels must be positive, got %d", n_mels);
+    if ((band_lo == nullptr) != (band_len == nullptr))
+        AP_FAIL(AP_ERR_INVALID, "band_lo and band_len must both be given or both be NULL");
+    P.out_mel = out;
+    P.fb = fb;
+    P.band_lo = band_lo;
+    P.band_len = band_len;
+    P.n_mels = n_mels;
+    P.power = power;
+    return AP_OK;
+}
+
+static inline int ap_prepare_irfft(ApIrfftParams &P, const float *S, int64_t B, int64_t T, int n_fft,
+                                   const float *tw, float *frames) {
+    if (!S || !tw || !frames) AP_FAIL(AP_ERR_INVALID, "irfft: NULL buffer");
+    if (B <= 0 || T <= 0 || n_fft <= 0) AP_FAIL(AP_ERR_INVALID, "irfft: empty input");
+    if (ap_make_plan(n_fft, &P.plan) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "n_fft=%d: cannot build FFT plan", n_fft);
+    if (ap_make_tile(&P.plan, T, &P.tile) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "n_fft=%d does not fit the %d KiB LDS of one CU", n_fft,
+                AP_LDS_MAX / 1024);
+    P.S = reinterpret_cast<const ap_float2 *>(S);
+    P.tw = reinterpret_cast<const ap_float2 *>(tw);
+    P.frames = frames;
+    P.T = T;
+    P.tiles_per_clip = (T + P.tile.G - 1) / P.tile.G;
+    P.n_bins = n_fft / 2 + 1;
+    if (P.tiles_per_clip * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "irfft: grid too large");
+    return AP_OK;
+}

@@ -1,0 +1,237 @@
+// Generic (any n_fft) kernels of the hot path: fused pad+frame+window+rFFT with a
+// complex or mel epilogue, irfft of frames, overlap-add, and the small copy
+// primitives the reference extension exposes.  One 256-thread workgroup handles a
+// tile of G consecutive frames of one clip, entirely in LDS.
+//
+// Replaces: pad_signal.metal:10-121, frame_signal.metal:10-36 (never materialised
+// here), `frames * win` + mx.fft.rfft (stft.py:129-130), the transpose
+// (stft.py:216), mx.abs/mx.power/mx.matmul (mel.py:321-350), mx.fft.irfft
+// (stft.py:295) and overlap_add.metal:16-55.
+#pragma once
+#include "fft_lds.h"
+
+#ifndef AP_PAD_CONSTANT
+#define AP_PAD_CONSTANT 0
+#define AP_PAD_EDGE 1
+#define AP_PAD_REFLECT 2
+#endif
+
+// Sample p of the virtually padded clip (p relative to the unpadded clip, may be
+// negative or >= L).  Index remaps follow pad_signal.metal:30-38 / stft.py:441-468.
+AP_DEV float ap_load_padded(const float *yb, int64_t L, int64_t p, int mode) {
+    if (p >= 0 && p < L) return yb[p];
+    if (mode == AP_PAD_CONSTANT) return 0.0f;
+    if (mode == AP_PAD_EDGE) return yb[p < 0 ? 0 : L - 1];
+    int64_t q = p < 0 ? -p : 2 * (L - 1) - p;   // reflect, edge sample not repeated
+    q = q < 0 ? 0 : (q >= L ? L - 1 : q);       // host validates pad <= L-1; clamp is a guard only
+    return yb[q];
+}
+
+AP_DEV float ap_pow_mag(float re, float im, float power) {
+    const float p2 = re * re + im * im;
+    if (power == 2.0f) return p2;
+    const float mag = sqrtf(p2);
+    if (power == 1.0f) return mag;
+    return powf(mag, power);
+}
+
+extern __shared__ __attribute__((aligned(16))) char ap_smem[];
+
+// EPI = 0: complex spectrum (B,F,T);  EPI = 1: mel (B,M,T)
+template <int EPI>
+__global__ void __launch_bounds__(AP_BLOCK) ap_stft_generic_kernel(ApStftParams P) {
+    const ApFftPlan &pl = P.plan;
+    const int G = P.tile.G, fstride = P.tile.fstride, nc = pl.nc, n = pl.n;
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
+    ap_float2 *bufB = bufA + (size_t)G * fstride;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / P.tiles_per_clip;
+    const int64_t t0 = (bid - b * P.tiles_per_clip) * G;
+    const int Gt = (int)((P.T - t0) < G ? (P.T - t0) : G);
+    const float *yb = P.y + b * P.L;
+
+    // ---- load: virtual pad + frame + window, packed as complex -----------------
+    for (int item = tid; item < G * nc; item += nthreads) {
+        const int g = item / nc;
+        const int c = item - g * nc;
+        ap_float2 z = ap_mk(0.0f, 0.0f);
+        if (g < Gt) {
+            const int64_t base = (t0 + g) * (int64_t)P.hop - P.pad;
+            if (pl.even) {
+                const int s = 2 * c;
+                z.x = P.window[s] * ap_load_padded(yb, P.L, base + s, P.pad_mode);
+                z.y = P.window[s + 1] * ap_load_padded(yb, P.L, base + s + 1, P.pad_mode);
+            } else {
+                z.x = P.window[c] * ap_load_padded(yb, P.L, base + c, P.pad_mode);
+            }
+        }
+        bufA[g * fstride + c] = z;
+    }
+    __syncthreads();
+
+    ap_float2 *Z = ap_fft_tile(bufA, bufB, pl, P.tw, G, fstride, tid, nthreads);
+    const int F = P.n_bins;
+
+    if (EPI == 0) {
+        // transposed store: frames of the tile are the fastest-varying lanes
+        for (int item = tid; item < F * G; item += nthreads) {
+            const int k = item / G;
+            const int g = item - k * G;
+            if (g < Gt) {
+                const ap_float2 *Zg = Z + g * fstride;
+                const ap_float2 X = pl.even ? ap_rfft_split(Zg, nc, k, P.tw) : Zg[k];
+                P.out_c[(b * F + k) * P.T + t0 + g] = X;
+            }
+        }
+    } else {
+        float *Pw = reinterpret_cast<float *>(Z == bufA ? bufB : bufA);
+        const int pstride = 2 * fstride;
+        for (int item = tid; item < F * G; item += nthreads) {
+            const int k = item / G;
+            const int g = item - k * G;
+            const ap_float2 *Zg = Z + g * fstride;
+            const ap_float2 X = pl.even ? ap_rfft_split(Zg, nc, k, P.tw) : Zg[k];
+            Pw[g * pstride + k] = ap_pow_mag(X.x, X.y, P.power);
+        }
+        __syncthreads();
+        // banded contraction: zeros outside [lo, lo+len) contribute exactly 0
+        for (int item = tid; item < P.n_mels * G; item += nthreads) {
+            const int m = item / G;
+            const int g = item - m * G;
+            if (g < Gt) {
+                const int lo = P.band_lo ? P.band_lo[m] : 0;
+                const int len = P.band_len ? P.band_len[m] : F;
+                const float *w = P.fb + (int64_t)m * F + lo;
+                const float *pp = Pw + g * pstride + lo;
+                float acc = 0.0f;
+                for (int i = 0; i < len; ++i) acc = fmaf(w[i], pp[i], acc);
+                P.out_mel[(b * P.n_mels + m) * P.T + t0 + g] = acc;
+            }
+        }
+    }
+    (void)n;
+}
+
+// irfft of each frame: S (B,F,T) -> frames (B,T,n).  Inverse via the forward
+// engine on conjugated data.
+__global__ void __launch_bounds__(AP_BLOCK) ap_irfft_generic_kernel(ApIrfftParams P) {
+    const ApFftPlan &pl = P.plan;
+    const int G = P.tile.G, fstride = P.tile.fstride, nc = pl.nc, n = pl.n;
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
+    ap_float2 *bufB = bufA + (size_t)G * fstride;
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / P.tiles_per_clip;
+    const int64_t t0 = (bid - b * P.tiles_per_clip) * G;
+    const int Gt = (int)((P.T - t0) < G ? (P.T - t0) : G);
+    const int F = P.n_bins;
+    const ap_float2 *Sb = P.S + b * F * P.T;
+
+    for (int item = tid; item < nc * G; item += nthreads) {
+        const int k = item / G;
+        const int g = item - k * G;
+        ap_float2 zc = ap_mk(0.0f, 0.0f);
+        if (g < Gt) {
+            const int64_t col = t0 + g;
+            if (pl.even) {
+                ap_float2 xk = Sb[(int64_t)k * P.T + col];
+                ap_float2 xm = Sb[(int64_t)(nc - k) * P.T + col];
+                if (k == 0) { xk.y = 0.0f; xm.y = 0.0f; }   // DC / Nyquist imaginary parts ignored
+                const float ax = xk.x + xm.x, ay = xk.y - xm.y;
+                const float dx = xk.x - xm.x, dy = xk.y + xm.y;
+                const ap_float2 w = P.tw[k];               // W_n^{-k} = (c, +s)
+                const float ox = w.x * dx - w.y * dy, oy = w.x * dy + w.y * dx;
+                zc = ap_mk(ax - oy, -(ay + ox));           // conj(E + iO) (x2, folded into 1/n)
+            } else {
+                const int half = (n - 1) / 2;
+                if (k <= half) {
+                    ap_float2 x = Sb[(int64_t)k * P.T + col];
+                    if (k == 0) x.y = 0.0f;
+                    zc = ap_mk(x.x, -x.y);
+                } else {
+                    zc = Sb[(int64_t)(n - k) * P.T + col];  // conj(conj(X[n-k]))
+                }
+            }
+        }
+        bufA[g * fstride + k] = zc;
+    }
+    __syncthreads();
+
+    ap_float2 *Y = ap_fft_tile(bufA, bufB, pl, P.tw, G, fstride, tid, nthreads);
+    const float scale = 1.0f / (float)n;
+    for (int item = tid; item < G * nc; item += nthreads) {
+        const int g = item / nc;
+        const int c = item - g * nc;
+        if (g < Gt) {
+            const ap_float2 v = Y[g * fstride + c];
+            float *dst = P.frames + ((b * P.T + t0 + g) * (int64_t)n);
+            if (pl.even) {
+                dst[2 * c] = v.x * scale;
+                dst[2 * c + 1] = -v.y * scale;
+            } else {
+                dst[c] = v.x * scale;
+            }
+        }
+    }
+}
+
+// overlap_add.metal:16-55 with an output offset (folds istft's centre trim).
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_overlap_add_kernel(const float *frames, const float *window, int64_t T, int n_fft, int hop,
+                      int64_t out_offset, int64_t out_len, int64_t blocks_per_row, float *out) {
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / blocks_per_row;
+    const int64_t i = (bid - b * blocks_per_row) * blockDim.x + threadIdx.x;
+    if (i >= out_len) return;
+    const int64_t p = i + out_offset;
+    int64_t first = (p - n_fft + 1 + hop - 1) / hop;   // ceil((p-N+1)/hop) for the non-negative case
+    if (p - n_fft + 1 <= 0) first = 0;
+    int64_t last = p / hop;
+    if (last >= T) last = T - 1;
+    float sum = 0.0f, wss = 0.0f;
+    const float *fb = frames + b * T * n_fft;
+    for (int64_t f = first; f <= last; ++f) {
+        const int s = (int)(p - f * hop);
+        const float w = window[s];
+        sum += w * fb[f * n_fft + s];
+        wss += w * w;
+    }
+    out[b * out_len + i] = sum / fmaxf(wss, 1e-8f);
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_pad_kernel(const float *x, int64_t B, int64_t L, int64_t pad, int mode, float *out) {
+    const int64_t Lo = L + 2 * pad;
+    const int64_t total = B * Lo;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / Lo;
+        const int64_t i = e - b * Lo;
+        out[e] = ap_load_padded(x + b * L, L, i - pad, mode);
+    }
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_frame_kernel(const float *x, int64_t B, int64_t L, int64_t T, int frame_length, int hop,
+                float *out) {
+    const int64_t total = B * T * frame_length;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t s = e % frame_length;
+        const int64_t bt = e / frame_length;
+        const int64_t t = bt % T;
+        const int64_t b = bt / T;
+        out[e] = x[b * L + t * hop + s];
+    }
+}
+
+// mode 0: |S| (mx.abs, stft.py:362)   mode 1: atan2(im, re) (stft.py:379)
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_complex_unary_kernel(const ap_float2 *S, int64_t n, int mode, float *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const ap_float2 v = S[e];
+        out[e] = mode == 0 ? sqrtf(v.x * v.x + v.y * v.y) : atan2f(v.y, v.x);
+    }
+}

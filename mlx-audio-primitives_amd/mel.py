@@ -1,0 +1,150 @@
+"""Mel scale, mel filterbank and mel spectrogram — same API as
+/root/reference/mlx_audio_primitives/mel.py.
+
+``hz_to_mel`` / ``mel_to_hz`` / the filterbank are host NumPy float64 exactly as in
+the reference (mel.py:31-168; the reference keeps these off the device on
+purpose).  ``melspectrogram`` is ONE fused kernel launch: the reference's
+stft -> abs -> power -> matmul chain (mel.py:310-350) with no (B,F,T) intermediate.
+"""
+
+from __future__ import annotations
+
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from . import _extension as _x
+from ._validation import validate_non_negative, validate_positive
+from .stft import _frame_count, _get_padded_window, _get_twiddles, _resolve_stft_args
+from .windows import _default_device
+
+# Slaney mel scale constants (reference mel.py:24-28)
+_SLANEY_F_MIN = 0.0
+_SLANEY_F_SP = 200.0 / 3
+_SLANEY_MIN_LOG_HZ = 1000.0
+_SLANEY_MIN_LOG_MEL = (_SLANEY_MIN_LOG_HZ - _SLANEY_F_MIN) / _SLANEY_F_SP
+_SLANEY_LOGSTEP = np.log(6.4) / 27.0
+
+
+def hz_to_mel(frequencies, htk: bool = False) -> np.ndarray:
+    """Hz -> mel on the host (reference mel.py:31-62)."""
+    f = np.asarray(frequencies)
+    if htk:
+        return 2595.0 * np.log10(1.0 + f / 700.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.where(
+            f < _SLANEY_MIN_LOG_HZ,
+            (f - _SLANEY_F_MIN) / _SLANEY_F_SP,
+            _SLANEY_MIN_LOG_MEL + np.log(f / _SLANEY_MIN_LOG_HZ) / _SLANEY_LOGSTEP,
+        )
+
+
+def mel_to_hz(mels, htk: bool = False) -> np.ndarray:
+    """mel -> Hz on the host (reference mel.py:65-93)."""
+    m = np.asarray(mels)
+    if htk:
+        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    return np.where(
+        m < _SLANEY_MIN_LOG_MEL,
+        _SLANEY_F_MIN + _SLANEY_F_SP * m,
+        _SLANEY_MIN_LOG_HZ * np.exp(_SLANEY_LOGSTEP * (m - _SLANEY_MIN_LOG_MEL)),
+    )
+
+
+@lru_cache(maxsize=64)
+def _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm):
+    """(bytes, shape, band_lo bytes, band_len bytes) — reference mel.py:100-168, plus
+    the per-filter non-zero span the banded contraction uses."""
+    n_freqs = 1 + n_fft // 2
+    fft_freqs = np.linspace(0, sr / 2.0, n_freqs)
+    mel_points = np.linspace(hz_to_mel(fmin, htk=htk), hz_to_mel(fmax, htk=htk), n_mels + 2)
+    hz_points = mel_to_hz(mel_points, htk=htk)
+    f_lower = hz_points[:-2, np.newaxis]
+    f_center = hz_points[1:-1, np.newaxis]
+    f_upper = hz_points[2:, np.newaxis]
+    freqs = fft_freqs[np.newaxis, :]
+    # the reference's +1e-10 guards and float32 cast before normalising are kept
+    lower = (freqs - f_lower) / (f_center - f_lower + 1e-10)
+    upper = (f_upper - freqs) / (f_upper - f_center + 1e-10)
+    fb = np.maximum(0, np.minimum(lower, upper)).astype(np.float32)
+    if norm == "slaney":
+        enorm = 2.0 / (hz_points[2: n_mels + 2] - hz_points[:n_mels])
+        fb *= enorm[:, np.newaxis]
+    elif norm is not None:
+        raise ValueError(f"Unknown norm: '{norm}'. Supported: 'slaney', None")
+    lo, ln = _band_spans(fb)
+    return fb.tobytes(), fb.shape, lo.tobytes(), ln.tobytes()
+
+
+def _band_spans(fb: np.ndarray):
+    """First bin and length of the smallest span holding every non-zero of each row."""
+    nz = fb != 0
+    any_nz = nz.any(axis=1)
+    first = np.where(any_nz, nz.argmax(axis=1), 0)
+    last = np.where(any_nz, fb.shape[1] - nz[:, ::-1].argmax(axis=1), 0)
+    return first.astype(np.int32), (last - first).astype(np.int32)
+
+
+_device_filterbank_cache: dict[tuple, tuple] = {}
+
+
+def _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, device):
+    validate_positive(n_mels, "n_mels")
+    validate_non_negative(fmin, "fmin")
+    if fmax is None:
+        fmax = sr / 2.0
+    if fmin >= fmax:
+        raise ValueError(f"fmin ({fmin}) must be less than fmax ({fmax})")
+    if fmax > sr / 2.0:
+        raise ValueError(f"fmax ({fmax}) cannot exceed Nyquist frequency ({sr / 2.0})")
+    dev = _default_device(device)
+    key = (sr, n_fft, n_mels, fmin, fmax, htk, norm, str(dev))
+    hit = _device_filterbank_cache.get(key)
+    if hit is not None:
+        return hit
+    fb_b, shape, lo_b, ln_b = _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm)
+    fb = torch.from_numpy(np.frombuffer(fb_b, dtype=np.float32).reshape(shape).copy()).to(dev)
+    lo = torch.from_numpy(np.frombuffer(lo_b, dtype=np.int32).copy()).to(dev)
+    ln = torch.from_numpy(np.frombuffer(ln_b, dtype=np.int32).copy()).to(dev)
+    _device_filterbank_cache[key] = (fb, lo, ln)
+    return fb, lo, ln
+
+
+def mel_filterbank(sr: int, n_fft: int, n_mels: int = 128, fmin: float = 0.0,
+                   fmax: float | None = None, htk: bool = False, norm: str | None = "slaney",
+                   device=None) -> torch.Tensor:
+    """Mel filterbank (n_mels, n_fft//2+1), float32, cached (reference mel.py:171-242)."""
+    return _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, device)[0]
+
+
+def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None = None,
+                   win_length: int | None = None, window="hann", center: bool = True,
+                   pad_mode: str = "constant", power: float = 2.0, n_mels: int = 128,
+                   fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
+                   norm: str | None = "slaney") -> torch.Tensor:
+    """mel_basis @ |stft(y)|**power (reference mel.py:245-352), fused on the GPU.
+
+    Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32."""
+    hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
+    y = _x.to_device_f32(y)
+    one_d = y.ndim == 1
+    if one_d:
+        y = y[None, :]
+    if y.ndim != 2:
+        raise ValueError(f"y must be 1D or 2D, got {y.ndim}D")
+    B, L = y.shape
+    dev = y.device
+    win = _get_padded_window(window, win_length, n_fft, dev)
+    T = _frame_count(L, n_fft, hop_length, center, pad_mode)
+    fb, lo, ln = _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
+    out = torch.empty((B, n_mels, T), dtype=torch.float32, device=dev)
+    if B > 0 and L > 0:
+        tw = _get_twiddles(n_fft, dev)
+        _x.check(_x.lib().ap_melspec_f32(
+            _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
+            _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(lo), _x.ptr(ln), int(n_mels),
+            float(power), _x.ptr(out), _x.stream_ptr(dev)))
+    else:
+        out.zero_()
+    return out[0] if one_d else out

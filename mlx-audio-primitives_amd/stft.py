@@ -1,0 +1,238 @@
+"""STFT / ISTFT — same API as /root/reference/mlx_audio_primitives/stft.py.
+
+The reference builds pad -> frame -> window -> rfft -> transpose out of five ops
+(stft.py:109-133,216) and irfft -> overlap-add out of three (stft.py:292-312).
+Here each direction is one call into libaudioprims_hip.so; this file only keeps
+the reference's argument handling, error messages, caches and length logic.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _extension as _x
+from .windows import get_window
+
+_WINDOW_SUM_EPSILON = 1e-8      # stft.py:21 (applied inside the overlap-add kernel)
+_WINDOW_CACHE_MAXSIZE = 32      # stft.py:24
+
+
+class _WindowCache:
+    """LRU of centre-padded windows per device, content-hashed for array windows
+    (reference stft.py:27-81)."""
+
+    def __init__(self, maxsize: int = _WINDOW_CACHE_MAXSIZE):
+        self._cache: dict[tuple, torch.Tensor] = {}
+        self._order: list[tuple] = []
+        self._maxsize = maxsize
+
+    @staticmethod
+    def _key(window, win_length, n_fft, device):
+        if isinstance(window, str):
+            return (window, win_length, n_fft, str(device))
+        w = window.detach().cpu().numpy() if isinstance(window, torch.Tensor) else np.asarray(window)
+        return ("array", hash(np.ascontiguousarray(w, dtype=np.float32).tobytes()), win_length,
+                n_fft, str(device))
+
+    def get(self, key):
+        if key in self._cache:
+            self._order.remove(key)
+            self._order.append(key)
+            return self._cache[key]
+        return None
+
+    def put(self, key, value):
+        while len(self._cache) >= self._maxsize and self._order:
+            self._cache.pop(self._order.pop(0), None)
+        self._cache[key] = value
+        self._order.append(key)
+
+    def clear(self):
+        self._cache.clear()
+        self._order.clear()
+
+
+_padded_window_cache = _WindowCache()
+_twiddle_cache: dict[tuple, torch.Tensor] = {}
+
+
+def _get_padded_window(window, win_length: int, n_fft: int, device) -> torch.Tensor:
+    """Window centre-padded to n_fft (reference stft.py:88-106)."""
+    key = _WindowCache._key(window, win_length, n_fft, device)
+    hit = _padded_window_cache.get(key)
+    if hit is not None:
+        return hit
+    win = get_window(window, win_length, fftbins=True, device=device).to(device)
+    if win_length < n_fft:
+        left = (n_fft - win_length) // 2
+        right = n_fft - win_length - left
+        win = torch.nn.functional.pad(win, (left, right))
+    win = win.contiguous()
+    _padded_window_cache.put(key, win)
+    return win
+
+
+def _get_twiddles(n_fft: int, device) -> torch.Tensor:
+    key = (n_fft, str(device))
+    t = _twiddle_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(_x.twiddle_table_host(n_fft)).to(device)
+        _twiddle_cache[key] = t
+    return t
+
+
+def _resolve_stft_args(n_fft, hop_length, win_length):
+    if hop_length is None:
+        hop_length = n_fft // 4
+    if win_length is None:
+        win_length = n_fft
+    if hop_length <= 0:
+        raise ValueError(f"hop_length must be positive, got {hop_length}")
+    if win_length <= 0:
+        raise ValueError(f"win_length must be positive, got {win_length}")
+    if win_length > n_fft:
+        raise ValueError(f"win_length ({win_length}) must be <= n_fft ({n_fft})")
+    if hop_length > n_fft:
+        raise ValueError(
+            f"hop_length ({hop_length}) should typically be <= n_fft ({n_fft})"
+        )
+    return int(hop_length), int(win_length)
+
+
+def _frame_count(signal_length: int, n_fft: int, hop_length: int, center: bool, pad_mode: str):
+    if pad_mode not in _x.PAD_MODES:
+        raise ValueError(
+            f"Unknown pad_mode: '{pad_mode}'. Supported: reflect, constant, edge"
+        )
+    padded = signal_length + (2 * (n_fft // 2) if center else 0)
+    if padded < n_fft:
+        raise ValueError(
+            f"Signal length ({padded}) must be >= frame_length ({n_fft}). "
+            f"Consider padding the signal."
+        )
+    return 1 + (padded - n_fft) // hop_length
+
+
+def stft(y, n_fft: int = 2048, hop_length: int | None = None, win_length: int | None = None,
+         window="hann", center: bool = True, pad_mode: str = "constant") -> torch.Tensor:
+    """Short-time Fourier transform (reference stft.py:136-222).
+
+    y: (samples,) or (batch, samples).  Returns complex64 (n_fft//2+1, n_frames) or
+    (batch, n_fft//2+1, n_frames), librosa layout."""
+    hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
+    y = _x.to_device_f32(y)
+    one_d = y.ndim == 1
+    if one_d:
+        y = y[None, :]
+    if y.ndim != 2:
+        raise ValueError(f"y must be 1D or 2D, got {y.ndim}D")
+    B, L = y.shape
+    dev = y.device
+    win = _get_padded_window(window, win_length, n_fft, dev)
+    T = _frame_count(L, n_fft, hop_length, center, pad_mode)
+    F = n_fft // 2 + 1
+    out = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
+    if B > 0 and L > 0:
+        tw = _get_twiddles(n_fft, dev)
+        _x.check(_x.lib().ap_stft_f32(_x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win),
+                                      _x.ptr(tw), int(bool(center)), _x.PAD_MODES[pad_mode], T,
+                                      _x.ptr(out), _x.stream_ptr(dev)))
+    else:
+        out.zero_()
+    S = torch.view_as_complex(out)
+    return S[0] if one_d else S
+
+
+def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = None,
+          n_fft: int | None = None, window="hann", center: bool = True,
+          length: int | None = None) -> torch.Tensor:
+    """Inverse STFT (reference stft.py:225-344): irfft, windowed overlap-add,
+    division by max(sum w^2, 1e-8), centre trim / length fix — one library call."""
+    if not isinstance(stft_matrix, torch.Tensor):
+        stft_matrix = torch.as_tensor(np.asarray(stft_matrix))
+    if stft_matrix.ndim not in (2, 3):
+        raise ValueError(f"stft_matrix must be 2D or 3D, got {stft_matrix.ndim}D")
+    two_d = stft_matrix.ndim == 2
+    if two_d:
+        stft_matrix = stft_matrix[None, :]
+    dev = stft_matrix.device if stft_matrix.is_cuda else _x.require_device()
+    _x.lib()
+    S = stft_matrix.to(device=dev, dtype=torch.complex64).contiguous()
+    B, F, T = S.shape
+    if n_fft is None:
+        n_fft = 2 * (F - 1)
+    if hop_length is None:
+        hop_length = n_fft // 4
+    if win_length is None:
+        win_length = n_fft
+    if F != n_fft // 2 + 1:
+        raise ValueError(
+            f"stft_matrix has {F} frequency bins but n_fft={n_fft} needs {n_fft // 2 + 1}"
+        )
+    win = _get_padded_window(window, win_length, n_fft, dev)
+    # output span (reference stft.py:300-338)
+    if length is not None:
+        padded_length = length + n_fft if center else length
+    else:
+        padded_length = n_fft + (T - 1) * hop_length
+    if center:
+        offset = n_fft // 2
+        out_len = length if length is not None else max(padded_length - 2 * offset, 0)
+        ola_len = out_len
+    else:
+        offset = 0
+        out_len = length if length is not None else padded_length
+        # beyond the natural span the reference zero-pads (stft.py:336-338)
+        ola_len = min(out_len, padded_length)
+    y = torch.zeros((B, out_len), dtype=torch.float32, device=dev) if ola_len < out_len else \
+        torch.empty((B, out_len), dtype=torch.float32, device=dev)
+    if B > 0 and T > 0 and ola_len > 0:
+        tw = _get_twiddles(n_fft, dev)
+        ws = torch.empty((B, T, n_fft), dtype=torch.float32, device=dev)
+        Sr = torch.view_as_real(S)
+        if ola_len == out_len:
+            tgt = y
+        else:
+            tgt = torch.empty((B, ola_len), dtype=torch.float32, device=dev)
+        _x.check(_x.lib().ap_istft_f32(_x.ptr(Sr), B, T, int(n_fft), int(hop_length), _x.ptr(win),
+                                       _x.ptr(tw), _x.ptr(ws), offset, ola_len, _x.ptr(tgt),
+                                       _x.stream_ptr(dev)))
+        if tgt is not y:
+            y[:, :ola_len] = tgt
+    return y[0] if two_d else y
+
+
+def magnitude(stft_matrix) -> torch.Tensor:
+    """|S| (reference stft.py:347-362)."""
+    return _complex_unary(stft_matrix, "ap_magnitude_f32")
+
+
+def phase(stft_matrix) -> torch.Tensor:
+    """atan2(imag, real) (reference stft.py:365-379)."""
+    return _complex_unary(stft_matrix, "ap_phase_f32")
+
+
+def _complex_unary(S, fn_name: str) -> torch.Tensor:
+    if not isinstance(S, torch.Tensor):
+        S = torch.as_tensor(np.asarray(S))
+    dev = S.device if S.is_cuda else _x.require_device()
+    _x.lib()
+    S = S.to(device=dev, dtype=torch.complex64).contiguous()
+    out = torch.empty(S.shape, dtype=torch.float32, device=dev)
+    n = S.numel()
+    if n:
+        _x.check(getattr(_x.lib(), fn_name)(_x.ptr(torch.view_as_real(S)), n, _x.ptr(out),
+                                            _x.stream_ptr(dev)))
+    return out
+
+
+def check_nola(window, hop_length: int, n_fft: int, tol: float = 1e-10) -> bool:
+    """Nonzero-overlap-add test on the host (reference stft.py:382-431)."""
+    win = get_window(window, n_fft, fftbins=True, device="cpu").numpy().astype(np.float64)
+    step = hop_length
+    n_bins = n_fft // step
+    binsums = sum(win[i * step:(i + 1) * step] ** 2 for i in range(n_bins))
+    if n_fft % step != 0:
+        binsums[: n_fft % step] += win[-(n_fft % step):] ** 2
+    return bool(np.min(binsums) > tol)

@@ -1,0 +1,142 @@
+"""ctypes bindings for tests/emu/libapemu.so (TEST INFRASTRUCTURE ONLY).
+
+The emulator runs the product's kernel source on the CPU (see emu_shim.h).  It is
+built on demand with g++ and is never imported by the product package.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "mlx-audio-primitives_amd", "csrc")
+LIB = os.path.join(HERE, "libapemu.so")
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+
+def build(force=False, sanitize=False):
+    srcs = [os.path.join(HERE, "emu_lib.cpp"), os.path.join(CSRC, "host_builders.cpp")]
+    deps = srcs + [os.path.join(HERE, "emu_shim.h")] + [
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")
+    ]
+    if not force and os.path.exists(LIB):
+        if os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps):
+            return LIB
+    cmd = ["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", LIB] + srcs
+    if sanitize:
+        cmd[1:1] = ["-fsanitize=address,undefined", "-g"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.emu_last_error.restype = ctypes.c_char_p
+        _lib.ap_twiddle_table_host.argtypes = [_int, _f32p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise ValueError(lib().emu_last_error().decode())
+
+
+def twiddles(n_fft):
+    tw = np.empty(2 * n_fft, np.float32)
+    _check(lib().ap_twiddle_table_host(n_fft, _p(tw)))
+    return tw
+
+
+def n_frames(L, n_fft, hop, center):
+    Lp = L + (2 * (n_fft // 2) if center else 0)
+    return 1 + (Lp - n_fft) // hop
+
+
+def stft(y, n_fft, hop, window, center=True, pad_mode=0):
+    y = np.ascontiguousarray(y, np.float32)
+    B, L = y.shape
+    T = n_frames(L, n_fft, hop, center)
+    out = np.zeros((B, n_fft // 2 + 1, T, 2), np.float32)
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(n_fft)
+    _check(lib().emu_stft_f32(_p(y), _i64(B), _i64(L), n_fft, hop, _p(window), _p(tw),
+                              int(center), pad_mode, _i64(T), _p(out)))
+    return out[..., 0] + 1j * out[..., 1]
+
+
+def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, banded=True):
+    y = np.ascontiguousarray(y, np.float32)
+    B, L = y.shape
+    T = n_frames(L, n_fft, hop, center)
+    fb = np.ascontiguousarray(fb, np.float32)
+    M = fb.shape[0]
+    out = np.zeros((B, M, T), np.float32)
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(n_fft)
+    if banded:
+        nz = fb != 0
+        lo = np.where(nz.any(1), nz.argmax(1), 0).astype(np.int32)
+        hi = np.where(nz.any(1), fb.shape[1] - nz[:, ::-1].argmax(1), 0).astype(np.int32)
+        ln = (hi - lo).astype(np.int32)
+        lo_p, ln_p = lo.ctypes.data_as(_i32p), ln.ctypes.data_as(_i32p)
+    else:
+        lo_p = ln_p = None
+    _check(lib().emu_melspec_f32(_p(y), _i64(B), _i64(L), n_fft, hop, _p(window), _p(tw),
+                                 int(center), pad_mode, _i64(T), _p(fb), lo_p, ln_p, M,
+                                 ctypes.c_float(power), _p(out)))
+    return out
+
+
+def irfft_frames(S, n_fft):
+    S = np.asarray(S)
+    B, F, T = S.shape
+    Si = np.ascontiguousarray(np.stack([S.real, S.imag], -1), np.float32)
+    frames = np.zeros((B, T, n_fft), np.float32)
+    tw = twiddles(n_fft)
+    _check(lib().emu_irfft_frames_f32(_p(Si), _i64(B), _i64(T), n_fft, _p(tw), _p(frames)))
+    return frames
+
+
+def overlap_add(frames, window, hop, out_len, out_offset=0):
+    frames = np.ascontiguousarray(frames, np.float32)
+    B, T, N = frames.shape
+    window = np.ascontiguousarray(window, np.float32)
+    out = np.zeros((B, out_len), np.float32)
+    _check(lib().emu_overlap_add_f32(_p(frames), _p(window), _i64(B), _i64(T), N, hop,
+                                     _i64(out_offset), _i64(out_len), _p(out)))
+    return out
+
+
+def pad(x, pad_len, mode):
+    x = np.ascontiguousarray(x, np.float32)
+    B, L = x.shape
+    out = np.zeros((B, L + 2 * pad_len), np.float32)
+    _check(lib().emu_pad_f32(_p(x), _i64(B), _i64(L), _i64(pad_len), mode, _p(out)))
+    return out
+
+
+def frame(x, frame_length, hop):
+    x = np.ascontiguousarray(x, np.float32)
+    B, L = x.shape
+    T = max(1 + (L - frame_length) // hop, 0)
+    out = np.zeros((B, T, frame_length), np.float32)
+    _check(lib().emu_frame_f32(_p(x), _i64(B), _i64(L), frame_length, hop, _p(out)))
+    return out

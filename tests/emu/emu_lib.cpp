@@ -1,0 +1,87 @@
+// TEST INFRASTRUCTURE ONLY.  Builds the product's kernel source for the CPU through
+// emu_shim.h and exposes emu_* twins of the C ABI that take HOST pointers.  Same
+// validation / geometry code as the HIP build (ap_launch.h), same kernel bodies
+// (kernels_generic.h); only the launch mechanism differs.
+#include "emu_shim.h"
+
+alignas(16) char ap_smem[160 * 1024];
+
+#include "../../mlx-audio-primitives_amd/csrc/ap_launch.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_generic.h"
+
+static thread_local char g_err[512] = "";
+char *ap_error_buffer() { return g_err; }
+void ap_set_error(const char *msg) { std::snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+extern "C" {
+
+const char *emu_last_error(void) { return g_err; }
+
+int emu_pad_f32(const float *x, int64_t B, int64_t L, int64_t pad, int mode, float *out) {
+    int grid;
+    int rc = ap_prepare_pad(x, B, L, pad, mode, out, &grid);
+    if (rc != AP_OK) return rc;
+    emu_launch(grid, AP_BLOCK, [&] { ap_pad_kernel(x, B, L, pad, mode, out); });
+    return AP_OK;
+}
+
+int emu_frame_f32(const float *x, int64_t B, int64_t L, int frame_length, int hop, float *out) {
+    int grid;
+    int64_t T;
+    int rc = ap_prepare_frame(x, B, L, frame_length, hop, out, &T, &grid);
+    if (rc != AP_OK) return rc;
+    emu_launch(grid, AP_BLOCK, [&] { ap_frame_kernel(x, B, L, T, frame_length, hop, out); });
+    return AP_OK;
+}
+
+int emu_overlap_add_f32(const float *frames, const float *window, int64_t B, int64_t T, int n_fft,
+                        int hop, int64_t out_offset, int64_t out_len, float *out) {
+    int64_t bpr;
+    int rc = ap_prepare_ola(frames, window, B, T, n_fft, hop, out_offset, out_len, out, &bpr);
+    if (rc != AP_OK) return rc;
+    emu_launch((unsigned)(bpr * B), AP_BLOCK, [&] {
+        ap_overlap_add_kernel(frames, window, T, n_fft, hop, out_offset, out_len, bpr, out);
+    });
+    return AP_OK;
+}
+
+int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                 const float *tw, int center, int pad_mode, int64_t T, float *out) {
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
+    if (rc != AP_OK) return rc;
+    P.out_c = reinterpret_cast<ap_float2 *>(out);
+    emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
+    return AP_OK;
+}
+
+int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                    const float *tw, int center, int pad_mode, int64_t T, const float *fb,
+                    const int32_t *band_lo, const int32_t *band_len, int n_mels, float power,
+                    float *out) {
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
+    if (rc != AP_OK) return rc;
+    rc = ap_prepare_mel(P, fb, band_lo, band_len, n_mels, power, out);
+    if (rc != AP_OK) return rc;
+    emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<1>(P); });
+    return AP_OK;
+}
+
+int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const float *tw,
+                         float *frames) {
+    ApIrfftParams P;
+    int rc = ap_prepare_irfft(P, S, B, T, n_fft, tw, frames);
+    if (rc != AP_OK) return rc;
+    emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_irfft_generic_kernel(P); });
+    return AP_OK;
+}
+
+int emu_complex_unary_f32(const float *S, int64_t n, int mode, float *out) {
+    emu_launch(ap_grid_1d(n, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] {
+        ap_complex_unary_kernel(reinterpret_cast<const ap_float2 *>(S), n, mode, out);
+    });
+    return AP_OK;
+}
+
+}  // extern "C"

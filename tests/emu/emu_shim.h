@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE ONLY — a minimal SIMT emulator so the *same kernel source*
+// (mlx-audio-primitives_amd/csrc/kernels_*.h) can be executed on the CPU: one OS
+// thread per GPU thread of a workgroup, std::barrier for __syncthreads(),
+// workgroups run one after another.  Used by tests/test_emu_kernels.py (and for
+// ASan/UBSan runs, which the GPU pool does not allow).  Never loaded by the
+// product package.
+#pragma once
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <thread>
+#include <vector>
+
+struct emu_dim3 {
+    unsigned x = 1, y = 1, z = 1;
+};
+
+inline thread_local emu_dim3 threadIdx, blockIdx;
+inline emu_dim3 blockDim, gridDim;
+inline std::barrier<> *emu_barrier_ptr = nullptr;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__
+#define __launch_bounds__(...)
+#define AP_DEV inline
+
+inline void __syncthreads() { emu_barrier_ptr->arrive_and_wait(); }
+
+alignas(16) inline char ap_smem_storage[160 * 1024];
+// kernels declare:  extern __shared__ __attribute__((aligned(16))) char ap_smem[];
+// -> after the macros above that is an extern char array; define it here.
+extern char ap_smem[];
+
+template <class F>
+void emu_launch(unsigned grid, unsigned block, F &&body) {
+    gridDim.x = grid;
+    blockDim.x = block;
+    std::barrier<> bar((std::ptrdiff_t)block);
+    emu_barrier_ptr = &bar;
+    std::vector<std::thread> threads;
+    threads.reserve(block);
+    for (unsigned t = 0; t < block; ++t) {
+        threads.emplace_back([&, t]() {
+            threadIdx.x = t;
+            for (unsigned b = 0; b < grid; ++b) {
+                blockIdx.x = b;
+                body();
+                bar.arrive_and_wait();   // workgroups of one launch share ap_smem
+            }
+        });
+    }
+    for (auto &th : threads) th.join();
+    emu_barrier_ptr = nullptr;
+}

@@ -1,0 +1,107 @@
+"""CPU: run the product's *kernel source* (kernels_generic.h, fft_lds.h) through the
+SIMT emulator in tests/emu and compare with the oracle.  Catches indexing, twiddle,
+radix-plan and pad-remap bugs before any GPU time is spent.  The emulator is test
+infrastructure; the product never loads it."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import audio_oracle as ao
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu_bind as eb  # noqa: E402
+
+PM = {"constant": 0, "edge": 1, "reflect": 2}
+
+STFT_CASES = [
+    # n_fft, hop, L, B, pad_mode, center   (radix plans: 16*16, 16*16*4, 8*5*5, 8*4, 3*5, 3*3*3, 11, 7*11, 16*16*16)
+    (512, 128, 4000, 2, "constant", True),
+    (2048, 512, 6000, 1, "reflect", True),
+    (400, 160, 3000, 3, "constant", True),
+    (64, 16, 500, 1, "edge", True),
+    (30, 7, 400, 2, "constant", False),
+    (27, 5, 300, 1, "constant", True),
+    (22, 11, 300, 1, "reflect", True),
+    (154, 30, 800, 1, "constant", True),
+    (8192, 2048, 20000, 1, "constant", True),
+    (2, 1, 40, 1, "constant", True),
+    (1, 1, 10, 1, "constant", True),
+]
+
+
+@pytest.mark.parametrize("n_fft,hop,L,B,pad_mode,center", STFT_CASES)
+def test_emu_stft(n_fft, hop, L, B, pad_mode, center):
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", n_fft, n_fft)
+    S = eb.stft(y, n_fft, hop, win, center, PM[pad_mode])
+    R = ao.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+    assert S.shape == R.shape
+    np.testing.assert_allclose(S, R, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("sr,n_fft,hop,M,L,B,power", [
+    (22050, 2048, 512, 128, 9000, 2, 2.0),
+    (16000, 400, 160, 80, 5000, 3, 2.0),
+    (22050, 1024, 256, 40, 5000, 1, 1.0),
+    (22050, 512, 128, 64, 4000, 1, 1.5),
+])
+def test_emu_melspec(sr, n_fft, hop, M, L, B, power):
+    rng = np.random.default_rng(M)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", n_fft, n_fft)
+    fb = ao.mel_filterbank(sr, n_fft, M)
+    R = ao.melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M, power=power)
+    banded = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=True)
+    dense = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=False)
+    np.testing.assert_allclose(banded, R, rtol=1e-4, atol=1e-4)
+    # skipping the zeros outside each filter's span must not change a single bit
+    np.testing.assert_array_equal(banded, dense)
+
+
+@pytest.mark.parametrize("n_fft,hop,L,B", [
+    (512, 128, 4000, 2), (2048, 512, 9000, 1), (400, 160, 3000, 2), (27, 5, 300, 1),
+    (30, 7, 300, 2), (8192, 2048, 20000, 1),
+])
+def test_emu_istft(n_fft, hop, L, B):
+    rng = np.random.default_rng(n_fft)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ao.stft(y, n_fft=n_fft, hop_length=hop)
+    fr = eb.irfft_frames(S, n_fft)
+    ref = np.fft.irfft(np.transpose(S, (0, 2, 1)).astype(np.complex128), n=n_fft, axis=-1)
+    np.testing.assert_allclose(fr, ref, atol=2e-6)
+    win = ao.padded_window("hann", n_fft, n_fft)
+    out = eb.overlap_add(fr, win, hop, L, out_offset=n_fft // 2)
+    np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=n_fft, length=L), atol=1e-5)
+    if n_fft % hop == 0 and n_fft // hop >= 4:
+        assert np.max(np.abs(out - y)) < 1e-5        # README.md:118
+
+
+def test_emu_irfft_ignores_dc_nyquist_imag():
+    rng = np.random.default_rng(5)
+    S = (rng.standard_normal((1, 33, 4)) + 1j * rng.standard_normal((1, 33, 4))).astype(np.complex64)
+    fr = eb.irfft_frames(S, 64)
+    ref = np.fft.irfft(np.transpose(S, (0, 2, 1)).astype(np.complex128), n=64, axis=-1)
+    np.testing.assert_allclose(fr, ref, atol=2e-6)
+
+
+def test_emu_overlap_add_direct_and_pad_frame():
+    rng = np.random.default_rng(9)
+    fr = rng.standard_normal((2, 9, 64)).astype(np.float32)
+    w = ao.get_window("hamming", 64)
+    for hop, out_len in ((16, 64 + 8 * 16), (64, 300), (1, 72), (24, 50)):
+        np.testing.assert_allclose(eb.overlap_add(fr, w, hop, out_len),
+                                   ao.overlap_add(fr, w, hop, out_len), rtol=1e-5, atol=1e-6)
+    x = np.arange(10, dtype=np.float32)[None]
+    assert eb.pad(x, 3, 2)[0].tolist() == [3, 2, 1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 8, 7, 6]
+    assert eb.pad(x, 3, 0)[0].tolist() == [0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 0, 0, 0]
+    assert eb.pad(x, 3, 1)[0].tolist() == [0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 9]
+    sig = rng.standard_normal((2, 100)).astype(np.float32)
+    np.testing.assert_array_equal(eb.frame(sig, 10, 5), ao.frame_signal(sig, 10, 5))
+    with pytest.raises(ValueError, match="reflect padding requires"):
+        eb.pad(x, 10, 2)
+    with pytest.raises(ValueError, match="must be >= frame_length"):
+        eb.frame(sig, 200, 5)
