@@ -20,6 +20,14 @@ from typing import Any
 
 import numpy as np
 
+# IMPORTANT: import torch BEFORE dlopen()ing the extension.  The PyTorch-ROCm wheel
+# bundles its own libamdhip64 (soname libamdhip64.so.7); loaded first, the dynamic
+# linker reuses it for our library's NEEDED libamdhip64.so.7, so kernels, streams and
+# allocations all live in ONE HIP runtime.  Loaded the other way round the process
+# ends up with two runtimes and the first launch fails with "no ROCm-capable device".
+# (The reference has the same ordering rule for mlx.core, _extension.py:22-25.)
+import torch  # noqa: F401
+
 from . import _build
 
 _c_f32p = ctypes.c_void_p
