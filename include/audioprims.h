@@ -126,16 +126,38 @@ int ap_stft_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop
                 const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
                 int64_t T, float *out /*dev (B,F,T,2)*/, void *stream);
 
+/* Mel contraction plan.  The filterbank is tiny and built on the host (mel.py:100-168),
+ * so its sparsity is analysed on the host once and shipped to the device next to it.
+ * ap_mel_plan_host fills a device-bound blob `plan` (int32 words, copy it to HBM) and a
+ * 16-int host descriptor `desc` that the caller hands back to ap_melspec_f32:
+ *   desc[0] flags   AP_PLAN_BANDED | AP_PLAN_PARTS      desc[1] n_mels   desc[2] n_bins
+ *   desc[3] total words of the blob
+ *   desc[4] off band_lo[M]   desc[5] off band_len[M]    (span holding all non-zeros of a filter)
+ *   desc[6] off parts[n_parts][4] = (row, first 4-bin group, n_groups<=4, first quad)
+ *   desc[7] n_parts          desc[8] off quads[n_quads][4] float weights   desc[9] n_quads
+ *   desc[10] off rowparts[M][AP_PLAN_RP] (part ids of a row, -1 padded)   desc[11] AP_PLAN_RP
+ * Parts split each filter's span into runs of <= 4 aligned 4-bin groups, sorted by
+ * length, so the wave kernel can contract with 16-byte LDS reads.  Zeros outside a
+ * span contribute exactly 0 to the reference's matmul (mel.py:344-350), so using the
+ * plan does not change which products are summed. */
+#define AP_PLAN_BANDED 1
+#define AP_PLAN_PARTS 2
+#define AP_PLAN_FORCE_GENERIC 256   /* caller-set in desc[0]: keep the generic LDS engine (tests) */
+#define AP_PLAN_RP 16
+#define AP_PLAN_DESC_INTS 16
+int64_t ap_mel_plan_words(const float *fb_host /*(M,F)*/, int n_mels, int n_bins);
+int ap_mel_plan_host(const float *fb_host /*(M,F)*/, int n_mels, int n_bins,
+                     int32_t *plan_host, int32_t *desc_host /*16 ints*/);
+
 /* melspectrogram: y (B,L) -> out (B, n_mels, T) = fb @ |stft(y)|^power, fused
  * (no (B,F,T) intermediate).  fb is the dense (n_mels, F) filterbank
- * (mel.py:100-168); band_lo/band_len (n_mels int32 each, may be NULL = dense)
- * give, per filter, the first bin and count of the span holding all its
- * non-zeros — zeros outside the span contribute exactly 0 to the reference's
- * matmul (mel.py:344-350), so skipping them does not change the result. */
+ * (mel.py:100-168); plan (device) + desc (host) come from ap_mel_plan_host, both may
+ * be NULL: dense contraction.  n_fft = 2048 with a PARTS plan runs the wave-per-frame
+ * kernel (kernels_wave.h); everything else the generic LDS engine (kernels_generic.h). */
 int ap_melspec_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop,
                    const float *window /*dev*/, const float *tw /*dev*/, int center,
                    int pad_mode, int64_t T, const float *fb /*dev (M,F)*/,
-                   const int32_t *band_lo /*dev*/, const int32_t *band_len /*dev*/,
+                   const int32_t *plan /*dev*/, const int32_t *desc /*host, 16 ints*/,
                    int n_mels, float power, float *out /*dev (B,M,T)*/, void *stream);
 
 /* irfft of every frame: S (B,F,T) complex64 -> frames (B,T,n_fft) float32,

@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "ap_version", "ap_last_error",
     "ap_generate_window_host", "ap_hz_to_mel_host", "ap_mel_to_hz_host",
     "ap_mel_filterbank_host", "ap_dct_matrix_host", "ap_twiddle_table_host", "ap_fft_supported",
+    "ap_mel_plan_words", "ap_mel_plan_host",
     "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
     "ap_stft_f32", "ap_melspec_f32", "ap_irfft_frames_f32", "ap_istft_f32",
     "ap_magnitude_f32", "ap_phase_f32",
@@ -72,6 +73,7 @@ def _declare(lib) -> None:
         "ap_overlap_add_f32": [P, P, L, L, I, I, L, L, P, P],
         "ap_stft_f32": [P, L, L, I, I, P, P, I, I, L, P, P],
         "ap_melspec_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P],
+        "ap_mel_plan_host": [P, I, I, P, P],
         "ap_irfft_frames_f32": [P, L, L, I, P, P, P],
         "ap_istft_f32": [P, L, L, I, I, P, P, P, L, L, P, P],
         "ap_magnitude_f32": [P, L, P, P],
@@ -81,6 +83,8 @@ def _declare(lib) -> None:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = I
+    lib.ap_mel_plan_words.argtypes = [P, I, I]
+    lib.ap_mel_plan_words.restype = L
 
 
 def _load() -> None:
@@ -205,6 +209,20 @@ def mel_filterbank_host(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False,
                                        -1.0 if fmax is None else float(fmax), int(bool(htk)),
                                        1 if norm == "slaney" else 0, out.ctypes.data))
     return out
+
+
+PLAN_BANDED, PLAN_PARTS, PLAN_FORCE_GENERIC = 1, 2, 256
+
+
+def mel_plan_host(fb: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Contraction plan of a dense (M, F) filterbank (include/audioprims.h:
+    ap_mel_plan_host): (device-bound int32 blob, 16-int host descriptor)."""
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    M, F = fb.shape
+    plan = np.zeros(int(lib().ap_mel_plan_words(fb.ctypes.data, M, F)), np.int32)
+    desc = np.zeros(16, np.int32)
+    check(lib().ap_mel_plan_host(fb.ctypes.data, M, F, plan.ctypes.data, desc.ctypes.data))
+    return plan, desc
 
 
 def dct_matrix_host(n_out: int, n_in: int, norm: str | None = "ortho") -> np.ndarray:

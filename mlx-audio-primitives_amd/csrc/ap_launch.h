@@ -8,6 +8,7 @@
 
 #include "../../include/audioprims.h"
 #include "ap_common.h"
+#include "ap_wave_params.h"
 
 char *ap_error_buffer();            // thread-local, 512 bytes (audioprims.hip / emu)
 
@@ -112,18 +113,66 @@ static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, in
     return AP_OK;
 }
 
-static inline int ap_prepare_mel(ApStftParams &P, const float *fb, const int32_t *band_lo,
-                                 const int32_t *band_len, int n_mels, float power, float *out) {
+static inline int ap_prepare_mel(ApStftParams &P, const float *fb, const int32_t *plan,
+                                 const int32_t *desc, int n_mels, float power, float *out) {
     if (!out || !fb) AP_FAIL(AP_ERR_INVALID, "melspectrogram: NULL buffer");
     if (n_mels <= 0) AP_FAIL(AP_ERR_INVALID, "n_mels must be positive, got %d", n_mels);
-    if ((band_lo == nullptr) != (band_len == nullptr))
-        AP_FAIL(AP_ERR_INVALID, "band_lo and band_len must both be given or both be NULL");
+    if ((plan == nullptr) != (desc == nullptr))
+        AP_FAIL(AP_ERR_INVALID, "plan and desc must both be given or both be NULL");
+    if (desc && (desc[1] != n_mels || desc[2] != P.n_bins))
+        AP_FAIL(AP_ERR_INVALID, "mel plan was built for (%d, %d), call has (%d, %d)", desc[1],
+                desc[2], n_mels, P.n_bins);
     P.out_mel = out;
     P.fb = fb;
-    P.band_lo = band_lo;
-    P.band_len = band_len;
+    const bool banded = plan && (desc[0] & AP_PLAN_BANDED);
+    P.band_lo = banded ? plan + desc[4] : nullptr;
+    P.band_len = banded ? plan + desc[5] : nullptr;
     P.n_mels = n_mels;
     P.power = power;
+    return AP_OK;
+}
+
+static inline int ap_align16(int x) { return (x + 15) & ~15; }
+
+// n_fft = 2048 wave-per-frame mel kernel (kernels_wave.h): eligibility and geometry
+static inline bool ap_mel_wave_eligible(int n_fft, const int32_t *plan, const int32_t *desc) {
+    return n_fft == 2048 && plan && desc && (desc[0] & AP_PLAN_PARTS) &&
+           !(desc[0] & AP_PLAN_FORCE_GENERIC);
+}
+
+static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P, int64_t B,
+                                      const int32_t *plan, const int32_t *desc, int *grid) {
+    const int M = P.n_mels;
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.parts = plan + desc[6];
+    W.n_parts = desc[7];
+    W.quads = reinterpret_cast<const float *>(plan + desc[8]);
+    W.n_quads = desc[9];
+    W.rowparts = plan + desc[10];
+    W.out = P.out_mel;
+    W.L = P.L;
+    W.T = P.T;
+    W.tiles_per_clip = (P.T + APW_G - 1) / APW_G;
+    W.n_tiles = W.tiles_per_clip * B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    W.pad_mode = P.pad_mode;
+    W.n_mels = M;
+    W.power = P.power;
+    int off = APW_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
+    W.off_pp = off; off += APW_WAVES * APW_PP_STRIDE * (int)sizeof(float);
+    W.off_wq = off; off += ap_align16(W.n_quads * 16);
+    W.off_parts = off; off += ap_align16(W.n_parts * 16);
+    W.off_partial = off; off += ap_align16(W.n_parts * 16);
+    W.off_macc = off; off += ap_align16(M * APW_G * 4);
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;     // does not fit: caller falls back to the generic engine
+    const int per_cu = off * 2 <= AP_LDS_MAX ? 2 : 1;
+    int64_t g = W.n_tiles < 256 * per_cu ? W.n_tiles : 256 * per_cu;   // persistent workgroups
+    *grid = (int)g;
     return AP_OK;
 }
 

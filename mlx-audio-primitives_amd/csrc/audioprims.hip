@@ -8,6 +8,7 @@
 
 #include "ap_launch.h"
 #include "kernels_generic.h"
+#include "kernels_wave.h"
 
 static thread_local char g_err[512] = "";
 
@@ -30,6 +31,15 @@ static int ap_allow_lds(K kernel, int bytes) {
             AP_FAIL(AP_ERR_HIP, "hipFuncSetAttribute(LDS=%d): %s", bytes, hipGetErrorString(e));
     }
     return AP_OK;
+}
+
+template <int PMODE>
+static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) {
+    int rc = ap_allow_lds(ap_mel2048_wave_kernel<PMODE>, W.lds_bytes);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_mel2048_wave_kernel<PMODE>, dim3(grid), dim3(256), W.lds_bytes,
+                       (hipStream_t)stream, W);
+    return ap_check_launch("ap_melspec_f32(wave)");
 }
 
 extern "C" {
@@ -86,13 +96,22 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
 
 int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
                    const float *tw, int center, int pad_mode, int64_t T, const float *fb,
-                   const int32_t *band_lo, const int32_t *band_len, int n_mels, float power,
-                   float *out, void *stream) {
+                   const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,
+                   void *stream) {
     ApStftParams P;
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
-    rc = ap_prepare_mel(P, fb, band_lo, band_len, n_mels, power, out);
+    rc = ap_prepare_mel(P, fb, plan, desc, n_mels, power, out);
     if (rc != AP_OK) return rc;
+    if (ap_mel_wave_eligible(n_fft, plan, desc)) {
+        ApMelWaveParams W;
+        int grid = 0;
+        if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
+            if (power == 2.0f) return ap_launch_mel_wave<2>(W, grid, stream);
+            if (power == 1.0f) return ap_launch_mel_wave<1>(W, grid, stream);
+            return ap_launch_mel_wave<0>(W, grid, stream);
+        }
+    }
     rc = ap_allow_lds(ap_stft_generic_kernel<1>, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(ap_stft_generic_kernel<1>, dim3((unsigned)(P.tiles_per_clip * B)),

@@ -2,6 +2,7 @@
 // basis, twiddle table.  These mirror the parts of the reference extension that are
 // deliberately run on the CPU stream in double precision
 // (windows.cpp:179-228, mel_filterbank.cpp:70-239, dct.cpp:24-101).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -168,6 +169,108 @@ int ap_twiddle_table_host(int n_fft, float *out_host) {
         out_host[2 * j] = (float)c;
         out_host[2 * j + 1] = (float)s;
     }
+    return AP_OK;
+}
+
+namespace {
+struct MelPart { int row, g0, ng, q0; };
+
+// spans + parts of a dense filterbank; returns total quads
+void mel_analyse(const float *fb, int M, int F, std::vector<int> &lo, std::vector<int> &len,
+                 std::vector<MelPart> &parts) {
+    lo.assign(M, 0);
+    len.assign(M, 0);
+    parts.clear();
+    for (int m = 0; m < M; ++m) {
+        int a = 0, b = 0;
+        bool any = false;
+        for (int k = 0; k < F; ++k)
+            if (fb[(size_t)m * F + k] != 0.0f) { if (!any) a = k; b = k + 1; any = true; }
+        if (!any) continue;
+        lo[m] = a;
+        len[m] = b - a;
+        const int gfirst = a >> 2, glast = (b - 1) >> 2;
+        for (int g = gfirst; g <= glast; g += 4) {
+            MelPart p;
+            p.row = m;
+            p.g0 = g;
+            p.ng = (glast - g + 1) < 4 ? (glast - g + 1) : 4;
+            p.q0 = 0;
+            parts.push_back(p);
+        }
+    }
+    // longest parts first: threads of one wave then run loops of (nearly) equal length
+    std::stable_sort(parts.begin(), parts.end(),
+                     [](const MelPart &x, const MelPart &y) { return x.ng > y.ng; });
+    int q = 0;
+    for (auto &p : parts) { p.q0 = q; q += p.ng; }
+}
+}  // namespace
+
+int64_t ap_mel_plan_words(const float *fb, int n_mels, int n_bins) {
+    if (!fb || n_mels <= 0 || n_bins <= 0) return 0;
+    std::vector<int> lo, len;
+    std::vector<MelPart> parts;
+    mel_analyse(fb, n_mels, n_bins, lo, len, parts);
+    int64_t quads = 0;
+    for (auto &p : parts) quads += p.ng;
+    return 2 * (int64_t)n_mels + 4 * (int64_t)parts.size() + 4 * quads +
+           (int64_t)n_mels * AP_PLAN_RP + 8;
+}
+
+int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int32_t *desc) {
+    if (!fb || !plan || !desc || n_mels <= 0 || n_bins <= 0) {
+        ap_set_error("mel plan: bad arguments");
+        return AP_ERR_INVALID;
+    }
+    const int M = n_mels, F = n_bins;
+    std::vector<int> lo, len;
+    std::vector<MelPart> parts;
+    mel_analyse(fb, M, F, lo, len, parts);
+    int64_t quads = 0;
+    for (auto &p : parts) quads += p.ng;
+    const int64_t words = ap_mel_plan_words(fb, M, F);
+    std::memset(plan, 0, sizeof(int32_t) * (size_t)words);
+    std::memset(desc, 0, sizeof(int32_t) * AP_PLAN_DESC_INTS);
+    int64_t off = 0;
+    const int64_t off_lo = off; off += M;
+    const int64_t off_len = off; off += M;
+    off += off & 3 ? 4 - (off & 3) : 0;                       // 16-byte align the int4 / float4 tables
+    const int64_t off_parts = off; off += 4 * (int64_t)parts.size();
+    const int64_t off_quads = off; off += 4 * quads;
+    const int64_t off_rp = off; off += (int64_t)M * AP_PLAN_RP;
+    for (int m = 0; m < M; ++m) { plan[off_lo + m] = lo[m]; plan[off_len + m] = len[m]; }
+    bool parts_ok = true;
+    std::vector<int> nrp(M, 0);
+    for (int64_t i = 0; i < M * (int64_t)AP_PLAN_RP; ++i) plan[off_rp + i] = -1;
+    float *wq = reinterpret_cast<float *>(plan + off_quads);
+    for (size_t i = 0; i < parts.size(); ++i) {
+        const MelPart &p = parts[i];
+        plan[off_parts + 4 * i + 0] = p.row;
+        plan[off_parts + 4 * i + 1] = p.g0;
+        plan[off_parts + 4 * i + 2] = p.ng;
+        plan[off_parts + 4 * i + 3] = p.q0;
+        for (int g = 0; g < p.ng; ++g)
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * (p.g0 + g) + e;
+                wq[4 * (size_t)(p.q0 + g) + e] = k < F ? fb[(size_t)p.row * F + k] : 0.0f;
+            }
+        if (nrp[p.row] < AP_PLAN_RP) plan[off_rp + (int64_t)p.row * AP_PLAN_RP + nrp[p.row]] = (int)i;
+        else parts_ok = false;
+        nrp[p.row]++;
+    }
+    desc[0] = AP_PLAN_BANDED | (parts_ok ? AP_PLAN_PARTS : 0);
+    desc[1] = M;
+    desc[2] = F;
+    desc[3] = (int32_t)words;
+    desc[4] = (int32_t)off_lo;
+    desc[5] = (int32_t)off_len;
+    desc[6] = (int32_t)off_parts;
+    desc[7] = (int32_t)parts.size();
+    desc[8] = (int32_t)off_quads;
+    desc[9] = (int32_t)quads;
+    desc[10] = (int32_t)off_rp;
+    desc[11] = AP_PLAN_RP;
     return AP_OK;
 }
 

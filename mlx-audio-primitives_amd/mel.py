@@ -54,8 +54,7 @@ def mel_to_hz(mels, htk: bool = False) -> np.ndarray:
 
 @lru_cache(maxsize=64)
 def _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm):
-    """(bytes, shape, band_lo bytes, band_len bytes) — reference mel.py:100-168, plus
-    the per-filter non-zero span the banded contraction uses."""
+    """(bytes, shape) — reference mel.py:100-168."""
     n_freqs = 1 + n_fft // 2
     fft_freqs = np.linspace(0, sr / 2.0, n_freqs)
     mel_points = np.linspace(hz_to_mel(fmin, htk=htk), hz_to_mel(fmax, htk=htk), n_mels + 2)
@@ -73,23 +72,14 @@ def _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm):
         fb *= enorm[:, np.newaxis]
     elif norm is not None:
         raise ValueError(f"Unknown norm: '{norm}'. Supported: 'slaney', None")
-    lo, ln = _band_spans(fb)
-    return fb.tobytes(), fb.shape, lo.tobytes(), ln.tobytes()
-
-
-def _band_spans(fb: np.ndarray):
-    """First bin and length of the smallest span holding every non-zero of each row."""
-    nz = fb != 0
-    any_nz = nz.any(axis=1)
-    first = np.where(any_nz, nz.argmax(axis=1), 0)
-    last = np.where(any_nz, fb.shape[1] - nz[:, ::-1].argmax(axis=1), 0)
-    return first.astype(np.int32), (last - first).astype(np.int32)
+    return fb.tobytes(), fb.shape
 
 
 _device_filterbank_cache: dict[tuple, tuple] = {}
 
 
 def _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, device):
+    """(filterbank, contraction plan blob on `device`, host plan descriptor), cached."""
     validate_positive(n_mels, "n_mels")
     validate_non_negative(fmin, "fmin")
     if fmax is None:
@@ -103,12 +93,13 @@ def _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, device):
     hit = _device_filterbank_cache.get(key)
     if hit is not None:
         return hit
-    fb_b, shape, lo_b, ln_b = _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm)
-    fb = torch.from_numpy(np.frombuffer(fb_b, dtype=np.float32).reshape(shape).copy()).to(dev)
-    lo = torch.from_numpy(np.frombuffer(lo_b, dtype=np.int32).copy()).to(dev)
-    ln = torch.from_numpy(np.frombuffer(ln_b, dtype=np.int32).copy()).to(dev)
-    _device_filterbank_cache[key] = (fb, lo, ln)
-    return fb, lo, ln
+    fb_b, shape = _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm)
+    fb_np = np.frombuffer(fb_b, dtype=np.float32).reshape(shape).copy()
+    plan_np, desc = _x.mel_plan_host(fb_np)
+    fb = torch.from_numpy(fb_np).to(dev)
+    plan = torch.from_numpy(plan_np).to(dev)
+    _device_filterbank_cache[key] = (fb, plan, desc)
+    return fb, plan, desc
 
 
 def mel_filterbank(sr: int, n_fft: int, n_mels: int = 128, fmin: float = 0.0,
@@ -137,13 +128,13 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
     dev = y.device
     win = _get_padded_window(window, win_length, n_fft, dev)
     T = _frame_count(L, n_fft, hop_length, center, pad_mode)
-    fb, lo, ln = _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
+    fb, plan, desc = _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
     out = torch.empty((B, n_mels, T), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
         tw = _get_twiddles(n_fft, dev)
         _x.check(_x.lib().ap_melspec_f32(
             _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
-            _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(lo), _x.ptr(ln), int(n_mels),
+            _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_mels),
             float(power), _x.ptr(out), _x.stream_ptr(dev)))
     else:
         out.zero_()

@@ -82,7 +82,20 @@ def stft(y, n_fft, hop, window, center=True, pad_mode=0):
     return out[..., 0] + 1j * out[..., 1]
 
 
-def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, banded=True):
+def mel_plan(fb):
+    fb = np.ascontiguousarray(fb, np.float32)
+    M, F = fb.shape
+    L = lib()
+    L.ap_mel_plan_words.restype = _i64
+    words = L.ap_mel_plan_words(_p(fb), M, F)
+    plan = np.zeros(words, np.int32)
+    desc = np.zeros(16, np.int32)
+    _check(L.ap_mel_plan_host(_p(fb), M, F, plan.ctypes.data_as(_i32p), desc.ctypes.data_as(_i32p)))
+    return plan, desc
+
+
+def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, banded=True,
+            force_generic=False):
     y = np.ascontiguousarray(y, np.float32)
     B, L = y.shape
     T = n_frames(L, n_fft, hop, center)
@@ -92,15 +105,14 @@ def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, bande
     window = np.ascontiguousarray(window, np.float32)
     tw = twiddles(n_fft)
     if banded:
-        nz = fb != 0
-        lo = np.where(nz.any(1), nz.argmax(1), 0).astype(np.int32)
-        hi = np.where(nz.any(1), fb.shape[1] - nz[:, ::-1].argmax(1), 0).astype(np.int32)
-        ln = (hi - lo).astype(np.int32)
-        lo_p, ln_p = lo.ctypes.data_as(_i32p), ln.ctypes.data_as(_i32p)
+        plan, desc = mel_plan(fb)
+        if force_generic:
+            desc[0] |= 256
+        plan_p, desc_p = plan.ctypes.data_as(_i32p), desc.ctypes.data_as(_i32p)
     else:
-        lo_p = ln_p = None
+        plan_p = desc_p = None
     _check(lib().emu_melspec_f32(_p(y), _i64(B), _i64(L), n_fft, hop, _p(window), _p(tw),
-                                 int(center), pad_mode, _i64(T), _p(fb), lo_p, ln_p, M,
+                                 int(center), pad_mode, _i64(T), _p(fb), plan_p, desc_p, M,
                                  ctypes.c_float(power), _p(out)))
     return out
 

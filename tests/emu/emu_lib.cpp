@@ -8,6 +8,7 @@ alignas(16) char ap_smem[160 * 1024];
 
 #include "../../mlx-audio-primitives_amd/csrc/ap_launch.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_generic.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_wave.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -57,13 +58,23 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
 
 int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
                     const float *tw, int center, int pad_mode, int64_t T, const float *fb,
-                    const int32_t *band_lo, const int32_t *band_len, int n_mels, float power,
-                    float *out) {
+                    const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out) {
     ApStftParams P;
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
-    rc = ap_prepare_mel(P, fb, band_lo, band_len, n_mels, power, out);
+    rc = ap_prepare_mel(P, fb, plan, desc, n_mels, power, out);
     if (rc != AP_OK) return rc;
+    if (ap_mel_wave_eligible(n_fft, plan, desc)) {
+        ApMelWaveParams W;
+        int grid = 0;
+        if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
+            if (grid > 3) grid = 3;   // exercise the persistent tile loop
+            if (power == 2.0f) emu_launch((unsigned)grid, 256, [&] { ap_mel2048_wave_kernel<2>(W); });
+            else if (power == 1.0f) emu_launch((unsigned)grid, 256, [&] { ap_mel2048_wave_kernel<1>(W); });
+            else emu_launch((unsigned)grid, 256, [&] { ap_mel2048_wave_kernel<0>(W); });
+            return AP_OK;
+        }
+    }
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<1>(P); });
     return AP_OK;
 }

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -27,8 +28,22 @@ inline std::barrier<> *emu_barrier_ptr = nullptr;
 #define __shared__
 #define __launch_bounds__(...)
 #define AP_DEV inline
+#define AP_HOST_EMU 1
 
+// ---- wave-level helpers used by kernels_wave.h: wave w = threads [64w, 64w+64) -----
+inline float emu_xchg[1024];
+inline std::barrier<> *emu_wave_barriers[16];
 inline void __syncthreads() { emu_barrier_ptr->arrive_and_wait(); }
+inline void emu_wave_sync() { emu_wave_barriers[threadIdx.x >> 6]->arrive_and_wait(); }
+inline float emu_lane_xor(float x, int mask) {
+    emu_xchg[threadIdx.x] = x;
+    emu_wave_sync();
+    const float y = emu_xchg[threadIdx.x ^ mask];
+    emu_wave_sync();
+    return y;
+}
+inline float ap_quad_xor1(float x) { return emu_lane_xor(x, 1); }
+inline float ap_quad_xor2(float x) { return emu_lane_xor(x, 2); }
 
 alignas(16) inline char ap_smem_storage[160 * 1024];
 // kernels declare:  extern __shared__ __attribute__((aligned(16))) char ap_smem[];
@@ -41,6 +56,12 @@ void emu_launch(unsigned grid, unsigned block, F &&body) {
     blockDim.x = block;
     std::barrier<> bar((std::ptrdiff_t)block);
     emu_barrier_ptr = &bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wbars;
+    for (unsigned w = 0; w * 64 < block; ++w) {
+        const unsigned n = block - w * 64 < 64 ? block - w * 64 : 64;
+        wbars.emplace_back(new std::barrier<>((std::ptrdiff_t)n));
+        emu_wave_barriers[w] = wbars.back().get();
+    }
     std::vector<std::thread> threads;
     threads.reserve(block);
     for (unsigned t = 0; t < block; ++t) {

@@ -55,11 +55,34 @@ def test_emu_melspec(sr, n_fft, hop, M, L, B, power):
     win = ao.padded_window("hann", n_fft, n_fft)
     fb = ao.mel_filterbank(sr, n_fft, M)
     R = ao.melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M, power=power)
-    banded = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=True)
+    banded = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=True, force_generic=True)
     dense = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=False)
     np.testing.assert_allclose(banded, R, rtol=1e-4, atol=1e-4)
     # skipping the zeros outside each filter's span must not change a single bit
     np.testing.assert_array_equal(banded, dense)
+    if n_fft == 2048:
+        wave = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=True)
+        np.testing.assert_allclose(wave, R, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("sr,M,L,B,power,pad_mode,kw", [
+    (22050, 128, 9000, 2, 2.0, "constant", {}),
+    (22050, 80, 30000, 1, 1.0, "reflect", dict(fmin=300.0, fmax=8000.0)),
+    (16000, 40, 2100, 3, 2.0, "edge", dict(htk=True)),
+    (22050, 128, 17 * 512, 1, 1.5, "constant", dict(norm=None)),
+])
+def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
+    """kernels_wave.h (n_fft=2048, wave per frame, DPP quad radix-4, LDS atomics) on the CPU."""
+    rng = np.random.default_rng(L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 2048, 2048)
+    fb = ao.mel_filterbank(sr, 2048, M, **kw)
+    plan, desc = eb.mel_plan(fb)
+    assert desc[0] & 2 and desc[1] == M
+    A = eb.melspec(y, 2048, 512, win, fb, power=power, pad_mode=PM[pad_mode])
+    R = ao.melspectrogram(y, sr=sr, n_fft=2048, hop_length=512, n_mels=M, power=power,
+                          pad_mode=pad_mode, **kw)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("n_fft,hop,L,B", [

@@ -195,29 +195,48 @@ def test_melspectrogram_whisper_and_variants(batch_signals):
                                rtol=1e-4, atol=1e-4)
 
 
-def test_melspectrogram_banded_equals_dense(random_signal):
-    """Skipping filter zeros must not change a bit (banded contraction)."""
+def test_melspectrogram_paths_agree(random_signal):
+    """Dense contraction, banded contraction (generic LDS engine) and the n_fft=2048 wave
+    kernel.  Skipping filter zeros must not change a bit on the generic engine; the wave
+    kernel sums in a different order and must stay within the reference tolerance."""
     y = dev(random_signal[None])
     n_fft, hop, M = 2048, 512, 128
-    fb = ap.mel_filterbank(22050, n_fft, M, device=y.device)
+    from mlx_audio_primitives_amd.mel import _mel_filterbank_full
     from mlx_audio_primitives_amd.stft import _get_padded_window, _get_twiddles
+    fb, plan, desc = _mel_filterbank_full(22050, n_fft, M, 0.0, None, False, "slaney", y.device)
+    assert desc[0] & ext.PLAN_PARTS
+    desc_generic = desc.copy()
+    desc_generic[0] |= ext.PLAN_FORCE_GENERIC
     win = _get_padded_window("hann", n_fft, n_fft, y.device)
     tw = _get_twiddles(n_fft, y.device)
     T = 1 + y.shape[1] // hop
-    outs = []
-    for banded in (True, False):
+    outs = {}
+    for name, pl, fl in (("dense", None, None), ("banded", plan.data_ptr(), desc_generic.ctypes.data),
+                         ("wave", plan.data_ptr(), desc.ctypes.data)):
         out = torch.empty((1, M, T), dtype=torch.float32, device=y.device)
-        if banded:
-            from mlx_audio_primitives_amd.mel import _mel_filterbank_full
-            _, lo, ln = _mel_filterbank_full(22050, n_fft, M, 0.0, None, False, "slaney", y.device)
-            lo_p, ln_p = lo.data_ptr(), ln.data_ptr()
-        else:
-            lo_p = ln_p = None
         ext.check(ext.lib().ap_melspec_f32(y.data_ptr(), 1, y.shape[1], n_fft, hop, win.data_ptr(),
-                                           tw.data_ptr(), 1, 0, T, fb.data_ptr(), lo_p, ln_p, M, 2.0,
+                                           tw.data_ptr(), 1, 0, T, fb.data_ptr(), pl, fl, M, 2.0,
                                            out.data_ptr(), ext.stream_ptr(y.device)))
-        outs.append(host(out))
-    np.testing.assert_array_equal(outs[0], outs[1])
+        outs[name] = host(out)
+    np.testing.assert_array_equal(outs["banded"], outs["dense"])
+    R = ao.melspectrogram(random_signal, sr=22050, n_mels=M)
+    np.testing.assert_allclose(outs["wave"][0], R, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(outs["wave"], outs["dense"], rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect", "edge"])
+@pytest.mark.parametrize("L", [2048, 5000, 22050, 16 * 512 * 3 + 17])
+def test_wave_kernel_edges(pad_mode, L):
+    """n_fft=2048 wave kernel: clip shorter than a tile, ragged last tile, every pad mode,
+    centre on/off, odd batch."""
+    rng = np.random.default_rng(L)
+    y = rng.standard_normal((3, L)).astype(np.float32)
+    for center in (True, False):
+        for power, n_mels in ((2.0, 128), (1.0, 40)):
+            kw = dict(sr=22050, n_fft=2048, hop_length=512, n_mels=n_mels, power=power,
+                      center=center, pad_mode=pad_mode)
+            np.testing.assert_allclose(host(ap.melspectrogram(dev(y), **kw)),
+                                       ao.melspectrogram(y, **kw), rtol=1e-4, atol=1e-4)
 
 
 # ------------------------------------------------------------------ _ext surface
