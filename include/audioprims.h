@@ -86,6 +86,15 @@ int ap_dct_matrix_host(int n_out, int n_in, int ortho, float *out_host);
  * quadrant points.  (Stands in for whatever mx.fft precomputes internally.) */
 int ap_twiddle_table_host(int n_fft, float *out_host);
 
+/* FIR of scipy.signal.resample_poly for the reduced ratio up/down (the reference's
+ * resample_poly is exactly that SciPy call, resample.py:279-281):
+ *   firwin(2*10*max(up,down)+1, 1/max(up,down), window=('kaiser', 5.0)) cast to float32,
+ *   times up (float32), with n_pre_pad = down - half_len % down zeros prepended.
+ * out_host must hold ap_resample_poly_ntaps(up, down) floats; n_pre_remove_out gets
+ * (half_len + n_pre_pad) / down, the number of leading outputs SciPy discards. */
+int ap_resample_poly_ntaps(int up, int down);
+int ap_resample_poly_taps_host(int up, int down, float *out_host, int *n_pre_remove_out);
+
 /* 1 if the LDS FFT engine can transform n_fft-point real frames, else 0. */
 int ap_fft_supported(int n_fft);
 
@@ -176,10 +185,60 @@ int ap_istft_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, int n_f
                  int64_t out_offset, int64_t out_len, float *out /*dev (B,out_len)*/,
                  void *stream);
 
+/* resample_poly core: x (B,L) -> out (B, n_out), n_out = ceil(L*up/down),
+ *   out[b,o] = sum_i taps[t - up*i] * x[b,i],  t = (o + n_pre_remove)*down,
+ * float32 accumulation in increasing i like SciPy's upfirdn (padtype "constant").
+ * up/down must already be gcd-reduced (resample.py:255-257). */
+int ap_resample_poly_f32(const float *x /*dev*/, int64_t B, int64_t L, int up, int down,
+                         const float *taps /*dev*/, int n_taps, int n_pre_remove,
+                         int64_t n_out, float *out /*dev*/, void *stream);
+
+/* linear-interpolation resampler (resample.py:142-212): positions j*(L-1)/(n_out-1)
+ * evaluated in float64 like the reference's NumPy code. */
+int ap_resample_linear_f32(const float *x /*dev*/, int64_t B, int64_t L, int64_t n_out,
+                           double scale, float *out /*dev*/, void *stream);
+
 /* magnitude / phase / |S|^p of a complex64 array of n elements —
  * stft.py:347-379 (mx.abs, mx.arctan2). */
 int ap_magnitude_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);
 int ap_phase_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * Tails of the hot path: Griffin-Lim projection, dB conversion, DCT (mfcc).
+ * ---------------------------------------------------------------------- */
+
+/* Griffin-Lim (griffinlim.py:123-178), element-wise over (B*F, T):
+ *   mode 0: rebuilt = S * exp(i*angles) (and tprev = rebuilt if tprev != NULL)
+ *   mode 1: R' = S * exp(i*atan2(R.im, R.re)); rebuilt = R' + momentum*(R' - tprev);
+ *           tprev = R' (when momentum > 0).  R has TR frames per row; frames >= TR
+ *           count as zero (the reference crops / zero-pads R to T, :156-165). */
+int ap_gl_project_f32(int mode, const float *S /*dev (BF,T)*/, const float *angles /*dev*/,
+                      const float *R /*dev (BF,TR,2)*/, int64_t TR, int64_t BF, int64_t T,
+                      float momentum, float *tprev /*dev (BF,T,2)*/, float *rebuilt /*dev*/,
+                      void *stream);
+
+/* max over n floats into *key_dev (uint32 order-preserving key; caller provides the
+ * 4-byte word, the call resets it first).  Used for ref=max and by ap_to_db_f32. */
+int ap_reduce_max_f32(const float *x /*dev*/, int64_t n, uint32_t *key_dev, void *stream);
+
+/* _to_db (convert.py:14-60): out = coef*log10(max(S,amin)/max(ref,amin)), then if
+ * top_db >= 0: out = max(out, GLOBAL max(out) - top_db).  ref = *ref_key_dev (a key from
+ * ap_reduce_max_f32) when ref_key_dev != NULL, else ref_value.  ws_dev: 4-byte scratch. */
+int ap_to_db_f32(const float *S /*dev*/, int64_t n, float coef, float amin, float ref_value,
+                 const uint32_t *ref_key_dev, float top_db, float *out /*dev*/,
+                 uint32_t *ws_dev, void *stream);
+
+/* db_to_power (div=10) / db_to_amplitude (div=20): ref * 10^(x/div) — convert.py:100-198 */
+int ap_from_db_f32(const float *x /*dev*/, int64_t n, float ref, float div, float *out /*dev*/,
+                   void *stream);
+
+/* dct(x, n, axis, norm) — bindings.cpp:337-368, dct.cpp:103-159, mfcc.py:69-140:
+ *   x viewed as (outer, n_in, inner); out[o,k,i] = row_scale[k] * sum_m C[k,m] x[o,m,i];
+ *   C is the (n_out, n_in) basis (ap_dct_matrix_host); row_scale may be NULL (lifter,
+ *   mfcc.py:277-282). */
+int ap_dct_f32(const float *x /*dev*/, const float *C /*dev (n_out,n_in)*/,
+               const float *row_scale /*dev or NULL*/, int64_t outer, int n_in, int64_t inner,
+               int n_out, float *out /*dev*/, void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,11 @@ kernel behind the C ABI in include/audioprims.h.  There is no CPU fallback.
 
 from ._extension import HAS_HIP_EXT, _ext
 from ._validation import validate_non_negative, validate_positive, validate_range
+from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
+from .griffinlim import griffinlim
 from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
+from .mfcc import dct, mfcc
+from .resample import resample, resample_poly
 from .stft import check_nola, istft, magnitude, phase, stft
 from .windows import get_window
 
@@ -18,5 +22,7 @@ __all__ = [
     "stft", "istft", "magnitude", "phase", "check_nola",
     "get_window",
     "hz_to_mel", "mel_to_hz", "mel_filterbank", "melspectrogram",
+    "griffinlim", "resample", "resample_poly",
+    "mfcc", "dct", "power_to_db", "db_to_power", "amplitude_to_db", "db_to_amplitude",
     "validate_positive", "validate_non_negative", "validate_range",
 ]

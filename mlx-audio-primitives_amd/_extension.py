@@ -49,6 +49,9 @@ ABI_SYMBOLS = [
     "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
     "ap_stft_f32", "ap_melspec_f32", "ap_irfft_frames_f32", "ap_istft_f32",
     "ap_magnitude_f32", "ap_phase_f32",
+    "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
+    "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
+    "ap_from_db_f32", "ap_dct_f32",
 ]
 
 HAS_HIP_EXT: bool = False
@@ -77,6 +80,15 @@ def _declare(lib) -> None:
         "ap_irfft_frames_f32": [P, L, L, I, P, P, P],
         "ap_istft_f32": [P, L, L, I, I, P, P, P, L, L, P, P],
         "ap_magnitude_f32": [P, L, P, P],
+        "ap_resample_poly_ntaps": [I, I],
+        "ap_resample_poly_taps_host": [I, I, P, P],
+        "ap_resample_poly_f32": [P, L, L, I, I, P, I, I, L, P, P],
+        "ap_resample_linear_f32": [P, L, L, L, ctypes.c_double, P, P],
+        "ap_gl_project_f32": [I, P, P, P, L, L, L, F, P, P, P],
+        "ap_reduce_max_f32": [P, L, P, P],
+        "ap_to_db_f32": [P, L, F, F, F, P, F, P, P, P],
+        "ap_from_db_f32": [P, L, F, F, P, P],
+        "ap_dct_f32": [P, P, P, L, I, L, I, P, P],
         "ap_phase_f32": [P, L, P, P],
     }
     for name, argtypes in sig.items():
@@ -334,6 +346,11 @@ class _Ext:
 
         t = torch.from_numpy(mel_filterbank_host(sr, n_fft, n_mels, fmin, fmax, htk, norm))
         return t.to(require_device()) if torch.cuda.is_available() else t
+
+    def dct(self, x, n=-1, axis=-1, norm="ortho", stream=None):
+        from .mfcc import dct as _dct
+
+        return _dct(x, n=None if n is None or n < 0 else n, axis=axis, norm=norm or None)
 
     def get_dct_matrix(self, n_out, n_in, norm="ortho", stream=None):
         import torch

@@ -67,6 +67,23 @@ static inline int ap_prepare_ola(const float *frames, const float *window, int64
     return AP_OK;
 }
 
+static inline int ap_prepare_resample_poly(const float *x, int64_t B, int64_t L, int up, int down,
+                                           const float *taps, int n_taps, int n_pre_remove,
+                                           int64_t n_out, const float *out, int64_t *blocks_per_row) {
+    if (!x || !taps || !out) AP_FAIL(AP_ERR_INVALID, "resample_poly: NULL buffer");
+    if (up <= 0) AP_FAIL(AP_ERR_INVALID, "up must be positive, got %d", up);
+    if (down <= 0) AP_FAIL(AP_ERR_INVALID, "down must be positive, got %d", down);
+    if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "resample_poly: signal must be non-empty");
+    if (n_taps <= 0 || n_pre_remove < 0) AP_FAIL(AP_ERR_INVALID, "resample_poly: bad filter");
+    const int64_t expect = (L * up + down - 1) / down;
+    if (n_out != expect)
+        AP_FAIL(AP_ERR_INVALID, "resample_poly: n_out mismatch (got %lld, expected %lld)",
+                (long long)n_out, (long long)expect);
+    *blocks_per_row = (n_out + AP_BLOCK - 1) / AP_BLOCK;
+    if (*blocks_per_row * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "resample_poly: grid too large");
+    return AP_OK;
+}
+
 static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, int64_t L, int n_fft,
                                   int hop, const float *window, const float *tw, int center,
                                   int pad_mode, int64_t T) {

@@ -9,6 +9,7 @@
 #include "ap_launch.h"
 #include "kernels_generic.h"
 #include "kernels_wave.h"
+#include "kernels_pointwise.h"
 
 static thread_local char g_err[512] = "";
 
@@ -138,6 +139,97 @@ int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const
     int rc = ap_irfft_frames_f32(S, B, T, n_fft, tw, frames_ws, stream);
     if (rc != AP_OK) return rc;
     return ap_overlap_add_f32(frames_ws, window, B, T, n_fft, hop, out_offset, out_len, out, stream);
+}
+
+int ap_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
+                         int n_taps, int n_pre_remove, int64_t n_out, float *out, void *stream) {
+    int64_t bpr;
+    int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_resample_poly_kernel, dim3((unsigned)(bpr * B)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
+    return ap_check_launch("ap_resample_poly_f32");
+}
+
+int ap_resample_linear_f32(const float *x, int64_t B, int64_t L, int64_t n_out, double scale,
+                           float *out, void *stream) {
+    if (!x || !out) AP_FAIL(AP_ERR_INVALID, "resample: NULL buffer");
+    if (B <= 0 || L <= 0 || n_out <= 0) AP_FAIL(AP_ERR_INVALID, "resample: empty signal");
+    hipLaunchKernelGGL(ap_resample_linear_kernel, dim3(ap_grid_1d(B * n_out, AP_BLOCK, kApStreamGrid)),
+                       dim3(AP_BLOCK), 0, (hipStream_t)stream, x, B, L, n_out, scale, out);
+    return ap_check_launch("ap_resample_linear_f32");
+}
+
+int ap_gl_project_f32(int mode, const float *S, const float *angles, const float *R, int64_t TR,
+                      int64_t BF, int64_t T, float momentum, float *tprev, float *rebuilt,
+                      void *stream) {
+    if (!S || !rebuilt) AP_FAIL(AP_ERR_INVALID, "griffinlim: NULL buffer");
+    if (mode == 0 && !angles) AP_FAIL(AP_ERR_INVALID, "griffinlim: angles missing");
+    if (mode == 1 && (!R || TR < 0)) AP_FAIL(AP_ERR_INVALID, "griffinlim: R missing");
+    if (mode == 1 && momentum > 0.0f && !tprev) AP_FAIL(AP_ERR_INVALID, "griffinlim: tprev missing");
+    if (mode != 0 && mode != 1) AP_FAIL(AP_ERR_INVALID, "griffinlim: bad mode");
+    if (BF <= 0 || T <= 0) return AP_OK;
+    hipLaunchKernelGGL(ap_gl_project_kernel, dim3(ap_grid_1d(BF * T, AP_BLOCK, kApStreamGrid)),
+                       dim3(AP_BLOCK), 0, (hipStream_t)stream, mode, S, angles,
+                       reinterpret_cast<const ap_float2 *>(R), TR, BF, T, momentum,
+                       reinterpret_cast<ap_float2 *>(tprev), reinterpret_cast<ap_float2 *>(rebuilt));
+    return ap_check_launch("ap_gl_project_f32");
+}
+
+static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
+
+int ap_reduce_max_f32(const float *x, int64_t n, uint32_t *key_dev, void *stream) {
+    if (!x || !key_dev || n <= 0) AP_FAIL(AP_ERR_INVALID, "reduce_max: bad arguments");
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+    if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(ap_reduce_max_kernel, dim3(ap_grid_1d(n, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK),
+                       AP_BLOCK * sizeof(float), (hipStream_t)stream, x, n, key_dev);
+    return ap_check_launch("ap_reduce_max_f32");
+}
+
+int ap_to_db_f32(const float *S, int64_t n, float coef, float amin, float ref_value,
+                 const uint32_t *ref_key_dev, float top_db, float *out, uint32_t *ws_dev,
+                 void *stream) {
+    if (n < 0 || (n > 0 && (!S || !out))) AP_FAIL(AP_ERR_INVALID, "to_db: bad buffer");
+    if (n == 0) return AP_OK;
+    const bool clip = top_db >= 0.0f;
+    if (clip && !ws_dev) AP_FAIL(AP_ERR_INVALID, "to_db: top_db needs a scratch word");
+    if (clip) {
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)ws_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+        if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+    }
+    const int grid = ap_grid_1d(n, AP_BLOCK, kApStreamGrid);
+    hipLaunchKernelGGL(ap_to_db_kernel, dim3(grid), dim3(AP_BLOCK), AP_BLOCK * sizeof(float),
+                       (hipStream_t)stream, S, n, coef, amin, ref_value, ref_key_dev, out,
+                       clip ? ws_dev : (uint32_t *)nullptr);
+    int rc = ap_check_launch("ap_to_db_f32");
+    if (rc != AP_OK || !clip) return rc;
+    hipLaunchKernelGGL(ap_clip_db_kernel, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, out, n,
+                       top_db, ws_dev);
+    return ap_check_launch("ap_to_db_f32(clip)");
+}
+
+int ap_from_db_f32(const float *x, int64_t n, float ref, float div, float *out, void *stream) {
+    if (n < 0 || (n > 0 && (!x || !out))) AP_FAIL(AP_ERR_INVALID, "from_db: bad buffer");
+    if (n == 0) return AP_OK;
+    hipLaunchKernelGGL(ap_from_db_kernel, dim3(ap_grid_1d(n, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, x, n, ref, div, out);
+    return ap_check_launch("ap_from_db_f32");
+}
+
+int ap_dct_f32(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
+               int64_t inner, int n_out, float *out, void *stream) {
+    if (!x || !C || !out) AP_FAIL(AP_ERR_INVALID, "dct: NULL buffer");
+    if (n_in <= 0 || n_out <= 0) AP_FAIL(AP_ERR_INVALID, "dct: sizes must be positive");
+    if (outer <= 0 || inner <= 0) return AP_OK;
+    const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
+    if (n_out <= 16)
+        hipLaunchKernelGGL(ap_dct_kernel<16>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
+                           row_scale, outer, n_in, inner, n_out, out);
+    else
+        hipLaunchKernelGGL(ap_dct_kernel<32>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
+                           row_scale, outer, n_in, inner, n_out, out);
+    return ap_check_launch("ap_dct_f32");
 }
 
 static int ap_complex_unary(const float *S, int64_t n, int mode, float *out, void *stream) {

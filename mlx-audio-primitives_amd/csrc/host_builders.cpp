@@ -274,6 +274,61 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     return AP_OK;
 }
 
+namespace {
+double bessel_i0(double x) {
+    // power series; |x| <= ~10 here (beta = 5): converges to double precision in < 40 terms
+    const double q = 0.25 * x * x;
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < 200; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+}  // namespace
+
+int ap_resample_poly_ntaps(int up, int down) {
+    if (up < 1 || down < 1) return 0;
+    const int max_rate = up > down ? up : down;
+    const int half_len = 10 * max_rate;
+    return 2 * half_len + 1 + (down - half_len % down);
+}
+
+int ap_resample_poly_taps_host(int up, int down, float *out, int *n_pre_remove_out) {
+    if (up < 1 || down < 1 || !out || !n_pre_remove_out) {
+        ap_set_error("resample_poly taps: bad arguments");
+        return AP_ERR_INVALID;
+    }
+    const int max_rate = up > down ? up : down;
+    const int half_len = 10 * max_rate;
+    const int numtaps = 2 * half_len + 1;
+    const int n_pre_pad = down - half_len % down;
+    const double fc = 1.0 / max_rate;             // cutoff relative to Nyquist
+    const double alpha = 0.5 * (numtaps - 1);
+    const double beta = 5.0;
+    std::vector<double> h(numtaps);
+    double sum = 0.0;
+    for (int n = 0; n < numtaps; ++n) {
+        const double m = n - alpha;
+        const double a = kPi * fc * m;
+        const double sinc = (m == 0.0) ? 1.0 : std::sin(a) / a;
+        const double r = (n - alpha) / alpha;
+        const double arg = 1.0 - r * r;
+        const double win = bessel_i0(beta * std::sqrt(arg > 0.0 ? arg : 0.0)) / bessel_i0(beta);
+        h[n] = fc * sinc * win;
+        sum += h[n];
+    }
+    for (int i = 0; i < n_pre_pad; ++i) out[i] = 0.0f;
+    for (int n = 0; n < numtaps; ++n) {
+        float v = (float)(h[n] / sum);            // firwin(...).astype(float32)
+        v *= (float)up;                           // h *= up in float32
+        out[n_pre_pad + n] = v;
+    }
+    *n_pre_remove_out = (half_len + n_pre_pad) / down;
+    return AP_OK;
+}
+
 int ap_fft_supported(int n_fft) {
     ApFftPlan pl;
     ApTile tl;

@@ -235,3 +235,45 @@ ap_complex_unary_kernel(const ap_float2 *S, int64_t n, int mode, float *out) {
         out[e] = mode == 0 ? sqrtf(v.x * v.x + v.y * v.y) : atan2f(v.y, v.x);
     }
 }
+
+// scipy.signal.resample_poly (upfirdn, zero padding) — reference resample.py:279-281.
+// One thread per output sample; float32 accumulation in increasing input index.
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_resample_poly_kernel(const float *x, int64_t L, int up, int down, const float *taps, int n_taps,
+                        int n_pre_remove, int64_t n_out, int64_t blocks_per_row, float *out) {
+#ifndef AP_HOST_EMU
+#pragma clang fp contract(off)   // SciPy's C loop rounds the product, then the sum: no FMA
+#endif
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / blocks_per_row;
+    const int64_t o = (bid - b * blocks_per_row) * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    const int64_t t = (o + n_pre_remove) * (int64_t)down;
+    int64_t i_hi = t / up;
+    if (i_hi > L - 1) i_hi = L - 1;
+    int64_t num = t - (n_taps - 1);
+    int64_t i_lo = num <= 0 ? 0 : (num + up - 1) / up;
+    const float *xb = x + b * L;
+    float acc = 0.0f;
+    for (int64_t i = i_lo; i <= i_hi; ++i) acc = acc + taps[t - (int64_t)up * i] * xb[i];
+    out[b * n_out + o] = acc;
+}
+
+// reference resample.py:183-195: float64 positions and interpolation, float32 result
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_resample_linear_kernel(const float *x, int64_t B, int64_t L, int64_t n_out, double scale, float *out) {
+    const int64_t total = B * n_out;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double step = n_out > 1 ? (double)(L - 1) / (double)(n_out - 1) : 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / n_out;
+        const int64_t j = e - b * n_out;
+        double pos = (double)j * step;
+        if (j == n_out - 1 && n_out > 1) pos = (double)(L - 1);
+        int64_t lo = (int64_t)floor(pos);
+        int64_t hi = lo + 1 < L ? lo + 1 : L - 1;
+        const double frac = pos - (double)lo;
+        const double v = (1.0 - frac) * (double)x[b * L + lo] + frac * (double)x[b * L + hi];
+        out[e] = (float)(v * scale);
+    }
+}

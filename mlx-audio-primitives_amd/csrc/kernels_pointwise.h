@@ -1,0 +1,147 @@
+// Element-wise / small-contraction kernels of the hot path's tails: Griffin-Lim phase
+// projection (griffinlim.py:123,168-178), dB conversions with the reference's GLOBAL
+// max clip (convert.py:42-60), the DCT-II contraction of mfcc (mfcc.py:135, dct.cpp:148).
+// All are HBM-bound streaming kernels: grid-stride, one element per lane per step.
+#pragma once
+#include "fft_lds.h"
+
+// mode 0: out = S * exp(i * angles)                        (griffinlim.py:123, init)
+// mode 1: R' = S * exp(i * atan2(R.im, R.re));  rebuilt = R' + m (R' - tprev); tprev = R'
+//         R is (B,F,TR); frames t >= TR are treated as zero (griffinlim.py:156-165 crop/pad)
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_gl_project_kernel(int mode, const float *S, const float *angles, const ap_float2 *R, int64_t TR,
+                     int64_t BF, int64_t T, float momentum, ap_float2 *tprev, ap_float2 *rebuilt) {
+    const int64_t total = BF * T;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        float ang;
+        if (mode == 0) {
+            ang = angles[e];
+        } else {
+            const int64_t row = e / T, t = e - row * T;
+            ap_float2 r = ap_mk(0.0f, 0.0f);
+            if (t < TR) r = R[row * TR + t];
+            ang = atan2f(r.y, r.x);
+        }
+        const float s = S[e];
+        const ap_float2 rn = ap_mk(s * cosf(ang), s * sinf(ang));
+        if (mode == 0) {
+            rebuilt[e] = rn;
+            if (tprev) tprev[e] = rn;
+        } else if (momentum > 0.0f) {
+            const ap_float2 tp = tprev[e];
+            rebuilt[e] = ap_mk(rn.x + momentum * (rn.x - tp.x), rn.y + momentum * (rn.y - tp.y));
+            tprev[e] = rn;
+        } else {
+            rebuilt[e] = rn;
+        }
+    }
+}
+
+// order-preserving float <-> uint key so a float max can use an integer atomic
+AP_DEV unsigned ap_fkey(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+AP_DEV float ap_fkey_inv(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+#ifdef AP_HOST_EMU
+inline void ap_atomic_max_u32(unsigned *p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+#else
+AP_DEV void ap_atomic_max_u32(unsigned *p, unsigned v) { atomicMax(p, v); }
+#endif
+
+// per-workgroup max of x -> one integer atomic per workgroup on *key (order-preserving key)
+__global__ void __launch_bounds__(AP_BLOCK) ap_reduce_max_kernel(const float *x, int64_t n, unsigned *key) {
+    float *red = reinterpret_cast<float *>(ap_smem);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float m = -INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) m = fmaxf(m, x[e]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ap_atomic_max_u32(key, ap_fkey(red[0]));
+}
+
+// pass 1 of _to_db (convert.py:42-54): out = coef * log10(max(S, amin) / max(ref, amin));
+// ref is *ref_key (max key of a previous reduction) when ref_key != NULL, else ref_value.
+// Also reduces max(out) into *max_key for the top_db clip.
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_to_db_kernel(const float *S, int64_t n, float coef, float amin, float ref_value,
+                const unsigned *ref_key, float *out, unsigned *max_key) {
+    float *red = reinterpret_cast<float *>(ap_smem);
+    const float ref = fmaxf(ref_key ? ap_fkey_inv(*ref_key) : ref_value, amin);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float m = -INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const float v = coef * log10f(fmaxf(S[e], amin) / ref);
+        out[e] = v;
+        m = fmaxf(m, v);
+    }
+    if (max_key) {
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) ap_atomic_max_u32(max_key, ap_fkey(red[0]));
+    }
+}
+
+// pass 2 (convert.py:56-58): out = max(out, max(out) - top_db), GLOBAL max over the whole array
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_clip_db_kernel(float *out, int64_t n, float top_db, const unsigned *max_key) {
+    const float floor_v = ap_fkey_inv(*max_key) - top_db;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+        out[e] = fmaxf(out[e], floor_v);
+}
+
+// db_to_power / db_to_amplitude (convert.py:100-129, 169-198): ref * 10^(x / div)
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_from_db_kernel(const float *x, int64_t n, float ref, float div, float *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+        out[e] = ref * powf(10.0f, x[e] / div);
+}
+
+// DCT-II (any small dense basis) along the middle axis of x viewed as (outer, n_in, inner):
+//   out[o, k, i] = row_scale[k] * sum_m C[k, m] * x[o, m, i]        (mfcc.py:135, :277-282)
+// One thread per (o, i); C[k, m] is wave-uniform (scalar loads); KT outputs per pass.
+template <int KT>
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_dct_kernel(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
+              int64_t inner, int n_out, float *out) {
+    const int64_t total = outer * inner;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t o = e / inner, i = e - o * inner;
+        const float *xp = x + o * n_in * inner + i;
+        float *op = out + o * n_out * inner + i;
+        for (int k0 = 0; k0 < n_out; k0 += KT) {
+            float acc[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k] = 0.0f;
+            for (int m = 0; m < n_in; ++m) {
+                const float v = xp[(int64_t)m * inner];
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+                    if (k0 + k < n_out) acc[k] = fmaf(C[(int64_t)(k0 + k) * n_in + m], v, acc[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+                if (k0 + k < n_out)
+                    op[(int64_t)(k0 + k) * inner] = row_scale ? acc[k] * row_scale[k0 + k] : acc[k];
+        }
+    }
+}

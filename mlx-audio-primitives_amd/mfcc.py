@@ -1,0 +1,85 @@
+"""DCT and MFCC — same API as /root/reference/mlx_audio_primitives/mfcc.py (``delta`` is a
+SciPy host call in the reference and outside the hot path).
+
+mfcc = fused melspectrogram kernel -> dB kernels (global-max clip) -> DCT contraction
+kernel applied straight to the (B, M, T) layout (no transposes, mfcc.py:265-271), with
+the lifter folded into the DCT epilogue.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _extension as _x
+from ._validation import validate_positive
+from .convert import power_to_db
+from .mel import melspectrogram
+
+_dct_cache: dict[tuple, torch.Tensor] = {}
+
+
+def _dct_matrix(n_out: int, n_in: int, norm, device) -> torch.Tensor:
+    """DCT-II basis (n_out, n_in): the float32 builder of the reference's native path
+    (dct.cpp:24-101, used by mfcc.py:113-115 when its extension is present)."""
+    key = (n_out, n_in, norm, str(device))
+    t = _dct_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(_x.dct_matrix_host(n_out, n_in, norm)).to(device)
+        _dct_cache[key] = t
+    return t
+
+
+def dct(x, type: int = 2, n: int | None = None, axis: int = -1, norm: str | None = "ortho",
+        _row_scale=None) -> torch.Tensor:
+    """DCT-II along `axis` (reference mfcc.py:69-140)."""
+    if type != 2:
+        raise ValueError(f"Only DCT type 2 is supported, got {type}")
+    x = _x.to_device_f32(x)
+    if x.ndim == 0:
+        raise ValueError("x must have at least one dimension")
+    ax = axis % x.ndim
+    n_in = x.shape[ax]
+    if n is None:
+        n = n_in
+    outer = int(np.prod(x.shape[:ax], dtype=np.int64)) if ax > 0 else 1
+    inner = int(np.prod(x.shape[ax + 1:], dtype=np.int64)) if ax + 1 < x.ndim else 1
+    C = _dct_matrix(int(n), int(n_in), norm, x.device)
+    out = torch.empty(x.shape[:ax] + (int(n),) + x.shape[ax + 1:], dtype=torch.float32,
+                      device=x.device)
+    if out.numel():
+        _x.check(_x.lib().ap_dct_f32(_x.ptr(x), _x.ptr(C),
+                                     None if _row_scale is None else _x.ptr(_row_scale), outer,
+                                     int(n_in), inner, int(n), _x.ptr(out), _x.stream_ptr(x.device)))
+    return out
+
+
+def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
+         hop_length: int | None = None, win_length: int | None = None, window="hann",
+         center: bool = True, pad_mode: str = "constant", power: float = 2.0, n_mels: int = 128,
+         fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
+         mel_norm: str | None = "slaney", dct_type: int = 2, norm: str | None = "ortho",
+         lifter: int = 0) -> torch.Tensor:
+    """Mel-frequency cepstral coefficients (reference mfcc.py:143-287).
+
+    Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames)."""
+    validate_positive(n_mfcc, "n_mfcc")
+    provided = S is not None
+    if S is None:
+        S = melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop_length, win_length=win_length,
+                           window=window, center=center, pad_mode=pad_mode, power=power,
+                           n_mels=n_mels, fmin=fmin, fmax=fmax, htk=htk, norm=mel_norm)
+    else:
+        S = _x.to_device_f32(S)
+    batched = S.ndim == 3
+    if not batched:
+        S = S[None, :]
+    # a provided S is taken to be log-power already (mfcc.py:253-258)
+    S_db = S if provided else power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0)
+    lift = None
+    if lifter > 0:
+        nn = np.arange(n_mfcc)
+        lift = torch.from_numpy(
+            (1 + (lifter / 2.0) * np.sin(np.pi * (nn + 1) / lifter)).astype(np.float32)).to(S_db.device)
+    M = dct(S_db, type=dct_type, n=n_mfcc, axis=1, norm=norm, _row_scale=lift)
+    return M if batched else M[0]

@@ -1,0 +1,112 @@
+"""Resampling — same API as /root/reference/mlx_audio_primitives/resample.py.
+
+The reference ships every resampler to the host (SciPy / NumPy, resample.py:97,123,
+279-281) and copies the result back.  Here ``resample_poly`` is a polyphase FIR kernel
+that reproduces scipy.signal.resample_poly for float32 input (same taps, same
+accumulation order), and ``res_type='linear'`` is a float64-position interpolation
+kernel.  ``res_type='fft'`` (scipy.signal.resample: one whole-clip FFT of arbitrary
+length) is not on the device yet and raises instead of silently running on the CPU.
+"""
+
+from __future__ import annotations
+
+import math
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from . import _extension as _x
+from ._validation import validate_positive
+
+_taps_cache: dict[tuple, tuple] = {}
+
+
+@lru_cache(maxsize=64)
+def _poly_taps_host(up: int, down: int) -> tuple[bytes, int]:
+    n = int(_x.lib().ap_resample_poly_ntaps(up, down))
+    taps = np.empty(n, np.float32)
+    import ctypes
+    npr = ctypes.c_int(0)
+    _x.check(_x.lib().ap_resample_poly_taps_host(up, down, taps.ctypes.data, ctypes.addressof(npr)))
+    return taps.tobytes(), npr.value
+
+
+def _poly_taps(up: int, down: int, device):
+    key = (up, down, str(device))
+    hit = _taps_cache.get(key)
+    if hit is None:
+        b, npr = _poly_taps_host(up, down)
+        hit = (torch.from_numpy(np.frombuffer(b, dtype=np.float32).copy()).to(device), npr)
+        _taps_cache[key] = hit
+    return hit
+
+
+def _as_rows(y, axis):
+    """Move `axis` last and flatten the rest: (rows, L) contiguous float32 in HBM."""
+    y = _x.to_device_f32(y)
+    if y.ndim == 0:
+        raise ValueError("y must have at least one dimension")
+    ym = torch.movedim(y, axis, -1) if y.ndim > 1 else y
+    lead = ym.shape[:-1]
+    return ym.reshape(-1, ym.shape[-1]).contiguous(), lead
+
+
+def _from_rows(out, lead, axis, ndim):
+    out = out.reshape(*lead, out.shape[-1])
+    return torch.movedim(out, -1, axis) if ndim > 1 else out
+
+
+def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constant") -> torch.Tensor:
+    """Polyphase resampling by up/down (reference resample.py:215-308 =
+    scipy.signal.resample_poly(y, up, down, axis, padtype='constant'))."""
+    validate_positive(up, "up")
+    validate_positive(down, "down")
+    g = math.gcd(int(up), int(down))
+    up, down = int(up) // g, int(down) // g
+    if up == 1 and down == 1:
+        return y                                         # resample.py:259
+    if padtype != "constant":
+        raise ValueError(
+            f"padtype='{padtype}' is not available on the HIP path (only 'constant', "
+            "the reference's default)")
+    ndim = y.ndim if hasattr(y, "ndim") else np.ndim(y)
+    rows, lead = _as_rows(y, axis)
+    R, L = rows.shape
+    n_out = (L * up + down - 1) // down
+    out = torch.empty((R, n_out), dtype=torch.float32, device=rows.device)
+    if R > 0 and L > 0:
+        taps, n_pre_remove = _poly_taps(up, down, rows.device)
+        _x.check(_x.lib().ap_resample_poly_f32(_x.ptr(rows), R, L, up, down, _x.ptr(taps),
+                                               taps.numel(), n_pre_remove, n_out, _x.ptr(out),
+                                               _x.stream_ptr(rows.device)))
+    return _from_rows(out, lead, axis, ndim)
+
+
+def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool = True,
+             scale: bool = False, axis: int = -1) -> torch.Tensor:
+    """Resample from orig_sr to target_sr (reference resample.py:21-212)."""
+    validate_positive(orig_sr, "orig_sr")
+    validate_positive(target_sr, "target_sr")
+    if orig_sr == target_sr:
+        return y
+    if res_type not in ("fft", "linear"):
+        raise ValueError(f"Unknown res_type: '{res_type}'. Supported: 'fft', 'linear'")
+    ndim = y.ndim if hasattr(y, "ndim") else np.ndim(y)
+    rows, lead = _as_rows(y, axis)
+    R, L = rows.shape
+    ratio = target_sr / orig_sr
+    n_out = int(np.round(L * ratio)) if fix else int(np.ceil(L * ratio))
+    if n_out == L:
+        return _from_rows(rows, lead, axis, ndim)
+    if res_type == "fft":
+        raise NotImplementedError(
+            "resample(res_type='fft') (scipy.signal.resample: a whole-clip FFT of arbitrary "
+            "length) has no HIP kernel yet; use res_type='linear' or resample_poly. "
+            "No CPU fallback is provided on purpose.")
+    out = torch.empty((R, n_out), dtype=torch.float32, device=rows.device)
+    if R > 0 and n_out > 0:
+        _x.check(_x.lib().ap_resample_linear_f32(_x.ptr(rows), R, L, n_out,
+                                                 float(ratio) if scale else 1.0, _x.ptr(out),
+                                                 _x.stream_ptr(rows.device)))
+    return _from_rows(out, lead, axis, ndim)

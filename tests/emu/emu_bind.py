@@ -152,3 +152,68 @@ def frame(x, frame_length, hop):
     out = np.zeros((B, T, frame_length), np.float32)
     _check(lib().emu_frame_f32(_p(x), _i64(B), _i64(L), frame_length, hop, _p(out)))
     return out
+
+
+def resample_poly_taps(up, down):
+    L = lib()
+    n = L.ap_resample_poly_ntaps(up, down)
+    taps = np.zeros(n, np.float32)
+    npr = ctypes.c_int(0)
+    _check(L.ap_resample_poly_taps_host(up, down, _p(taps), ctypes.byref(npr)))
+    return taps, npr.value
+
+
+def resample_poly(x, up, down):
+    x = np.ascontiguousarray(x, np.float32)
+    B, L = x.shape
+    taps, npr = resample_poly_taps(up, down)
+    n_out = (L * up + down - 1) // down
+    out = np.zeros((B, n_out), np.float32)
+    _check(lib().emu_resample_poly_f32(_p(x), _i64(B), _i64(L), up, down, _p(taps), len(taps), npr,
+                                       _i64(n_out), _p(out)))
+    return out
+
+
+def resample_linear(x, n_out, scale=1.0):
+    x = np.ascontiguousarray(x, np.float32)
+    B, L = x.shape
+    out = np.zeros((B, n_out), np.float32)
+    _check(lib().emu_resample_linear_f32(_p(x), _i64(B), _i64(L), _i64(n_out),
+                                         ctypes.c_double(scale), _p(out)))
+    return out
+
+
+def gl_project(mode, S, angles=None, R=None, momentum=0.99, tprev=None):
+    S = np.ascontiguousarray(S, np.float32)
+    B, F, T = S.shape
+    reb = np.zeros((B, F, T, 2), np.float32)
+    tp = np.zeros((B, F, T, 2), np.float32) if tprev is None else \
+        np.ascontiguousarray(np.stack([tprev.real, tprev.imag], -1), np.float32)
+    ang_p = _p(np.ascontiguousarray(angles, np.float32)) if angles is not None else None
+    if R is not None:
+        Rr = np.ascontiguousarray(np.stack([R.real, R.imag], -1), np.float32)
+        R_p, TR = _p(Rr), R.shape[-1]
+    else:
+        R_p, TR = None, 0
+    _check(lib().emu_gl_project_f32(mode, _p(S), ang_p, R_p, _i64(TR), _i64(B * F), _i64(T),
+                                    ctypes.c_float(momentum), _p(tp), _p(reb)))
+    return reb[..., 0] + 1j * reb[..., 1], tp[..., 0] + 1j * tp[..., 1]
+
+
+def to_db(S, coef=10.0, amin=1e-10, ref=1.0, ref_is_max=False, top_db=80.0):
+    S = np.ascontiguousarray(S, np.float32)
+    out = np.zeros_like(S)
+    _check(lib().emu_to_db_f32(_p(S), _i64(S.size), ctypes.c_float(coef), ctypes.c_float(amin),
+                               ctypes.c_float(ref), int(ref_is_max),
+                               ctypes.c_float(-1.0 if top_db is None else top_db), _p(out)))
+    return out
+
+
+def dct(x, C, outer, n_in, inner, row_scale=None):
+    x = np.ascontiguousarray(x, np.float32)
+    C = np.ascontiguousarray(C, np.float32)
+    n_out = C.shape[0]
+    out = np.zeros(outer * n_out * inner, np.float32)
+    rs = _p(np.ascontiguousarray(row_scale, np.float32)) if row_scale is not None else None
+    _check(lib().emu_dct_f32(_p(x), _p(C), rs, _i64(outer), n_in, _i64(inner), n_out, _p(out)))
+    return out

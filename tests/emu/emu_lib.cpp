@@ -9,6 +9,7 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/ap_launch.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_generic.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_pointwise.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -85,6 +86,57 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
     int rc = ap_prepare_irfft(P, S, B, T, n_fft, tw, frames);
     if (rc != AP_OK) return rc;
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_irfft_generic_kernel(P); });
+    return AP_OK;
+}
+
+int emu_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
+                          int n_taps, int n_pre_remove, int64_t n_out, float *out) {
+    int64_t bpr;
+    int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
+    if (rc != AP_OK) return rc;
+    emu_launch((unsigned)(bpr * B), AP_BLOCK, [&] {
+        ap_resample_poly_kernel(x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
+    });
+    return AP_OK;
+}
+
+int emu_resample_linear_f32(const float *x, int64_t B, int64_t L, int64_t n_out, double scale, float *out) {
+    emu_launch(ap_grid_1d(B * n_out, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] {
+        ap_resample_linear_kernel(x, B, L, n_out, scale, out);
+    });
+    return AP_OK;
+}
+
+int emu_gl_project_f32(int mode, const float *S, const float *angles, const float *R, int64_t TR,
+                       int64_t BF, int64_t T, float momentum, float *tprev, float *rebuilt) {
+    emu_launch(ap_grid_1d(BF * T, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] {
+        ap_gl_project_kernel(mode, S, angles, reinterpret_cast<const ap_float2 *>(R), TR, BF, T, momentum,
+                             reinterpret_cast<ap_float2 *>(tprev), reinterpret_cast<ap_float2 *>(rebuilt));
+    });
+    return AP_OK;
+}
+
+int emu_to_db_f32(const float *S, int64_t n, float coef, float amin, float ref_value, int ref_is_max,
+                  float top_db, float *out) {
+    unsigned keys[2] = {0x007FFFFFu, 0x007FFFFFu};
+    const int grid = ap_grid_1d(n, AP_BLOCK, kApStreamGrid);
+    if (ref_is_max) emu_launch(grid, AP_BLOCK, [&] { ap_reduce_max_kernel(S, n, &keys[1]); });
+    const bool clip = top_db >= 0.0f;
+    emu_launch(grid, AP_BLOCK, [&] {
+        ap_to_db_kernel(S, n, coef, amin, ref_value, ref_is_max ? &keys[1] : nullptr, out,
+                        clip ? &keys[0] : nullptr);
+    });
+    if (clip) emu_launch(grid, AP_BLOCK, [&] { ap_clip_db_kernel(out, n, top_db, &keys[0]); });
+    return AP_OK;
+}
+
+int emu_dct_f32(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
+                int64_t inner, int n_out, float *out) {
+    const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
+    if (n_out <= 16)
+        emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<16>(x, C, row_scale, outer, n_in, inner, n_out, out); });
+    else
+        emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32>(x, C, row_scale, outer, n_in, inner, n_out, out); });
     return AP_OK;
 }
 

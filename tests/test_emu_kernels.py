@@ -128,3 +128,47 @@ def test_emu_overlap_add_direct_and_pad_frame():
         eb.pad(x, 10, 2)
     with pytest.raises(ValueError, match="must be >= frame_length"):
         eb.frame(sig, 200, 5)
+
+
+def test_emu_resample_poly_bit_exact_vs_scipy():
+    """The polyphase kernel reproduces scipy.signal.resample_poly (= the reference's
+    resample_poly, resample.py:279-281) bit for bit on the CPU build."""
+    from conftest import load_golden
+    z = load_golden("resample_scipy.npz")
+    for tag, up, down in (("p13", 1, 3), ("p21", 2, 1), ("p32", 3, 2), ("p147_160", 147, 160)):
+        x = z[f"{tag}_y"]
+        x2 = x if x.ndim == 2 else x[None]
+        want = z[f"{tag}_out"]
+        want = want if want.ndim == 2 else want[None]
+        np.testing.assert_array_equal(eb.resample_poly(x2, up, down), want)
+    x = np.random.default_rng(0).standard_normal((2, 1000)).astype(np.float32)
+    np.testing.assert_array_equal(eb.resample_linear(x, 733), ao.resample(x, 1000, 733, res_type="linear"))
+    np.testing.assert_allclose(eb.resample_linear(x, 1500, scale=1.5),
+                               ao.resample(x, 1000, 1500, res_type="linear", scale=True), rtol=1e-6)
+
+
+def test_emu_db_dct_and_gl_projection():
+    rng = np.random.default_rng(3)
+    S = (rng.standard_normal((3, 40, 50)).astype(np.float32)) ** 2
+    np.testing.assert_allclose(eb.to_db(S), ao.power_to_db(S), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(eb.to_db(S, coef=20.0, amin=1e-5, ref_is_max=True, top_db=None),
+                               ao.amplitude_to_db(S, ref=np.max, top_db=None), rtol=1e-5, atol=1e-4)
+    x = rng.standard_normal((3, 40, 50)).astype(np.float32)
+    C = ao.dct_matrix(13, 40)
+    got = eb.dct(x, C, 3, 40, 50).reshape(3, 13, 50)
+    np.testing.assert_allclose(got, ao.dct(x, n=13, axis=1), rtol=1e-4, atol=1e-4)
+    got = eb.dct(x, ao.dct_matrix(20, 50), 120, 50, 1).reshape(3, 40, 20)
+    np.testing.assert_allclose(got, ao.dct(x, n=20, axis=-1), rtol=1e-4, atol=1e-4)
+    # Griffin-Lim projection: init and one momentum step, with a shorter R (zero-padded frames)
+    Sm = np.abs(rng.standard_normal((2, 9, 7))).astype(np.float32)
+    ang = rng.uniform(-np.pi, np.pi, Sm.shape).astype(np.float32)
+    reb, tp = eb.gl_project(0, Sm, angles=ang)
+    want = (Sm * np.exp(1j * ang.astype(np.float64))).astype(np.complex64)
+    np.testing.assert_allclose(reb, want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tp, want, rtol=1e-5, atol=1e-6)
+    R = (rng.standard_normal((2, 9, 5)) + 1j * rng.standard_normal((2, 9, 5))).astype(np.complex64)
+    reb2, tp2 = eb.gl_project(1, Sm, R=R, momentum=0.99, tprev=want)
+    Rp = np.pad(R, [(0, 0), (0, 0), (0, 2)])
+    Rn = (Sm * np.exp(1j * np.angle(Rp).astype(np.float64))).astype(np.complex64)
+    np.testing.assert_allclose(tp2, Rn, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(reb2, Rn + np.float32(0.99) * (Rn - want), rtol=1e-4, atol=1e-5)
