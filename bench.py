@@ -135,10 +135,9 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
 
-    if dist is not None:
-        tt = torch.tensor([wall, dev_ms], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(tt[0]), float(tt[1])
+    from mlx_audio_primitives_amd import sharding
+    wall = sharding.max_over_ranks(wall, device=device)        # slowest rank decides
+    dev_ms = sharding.max_over_ranks(dev_ms, device=device)
 
     if rank == 0:
         frames_per_step = world * B * T
