@@ -142,9 +142,9 @@ int ap_stft_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop
  *   desc[0] flags   AP_PLAN_BANDED | AP_PLAN_PARTS      desc[1] n_mels   desc[2] n_bins
  *   desc[3] total words of the blob
  *   desc[4] off band_lo[M]   desc[5] off band_len[M]    (span holding all non-zeros of a filter)
- *   desc[6] off parts[n_parts][4] = (row, first 4-bin group, n_groups<=4, first quad)
+ *   desc[6] off parts[n_parts][4] = (slot, first 4-bin group, n_groups<=4, first quad)
  *   desc[7] n_parts          desc[8] off quads[n_quads][4] float weights   desc[9] n_quads
- *   desc[10] off rowparts[M][AP_PLAN_RP] (part ids of a row, -1 padded)   desc[11] AP_PLAN_RP
+ *   desc[10] off rowstart[M+1]: row m's partial sums live in slots [rowstart[m], rowstart[m+1])
  * Parts split each filter's span into runs of <= 4 aligned 4-bin groups, sorted by
  * length, so the wave kernel can contract with 16-byte LDS reads.  Zeros outside a
  * span contribute exactly 0 to the reference's matmul (mel.py:344-350), so using the
@@ -152,7 +152,6 @@ int ap_stft_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop
 #define AP_PLAN_BANDED 1
 #define AP_PLAN_PARTS 2
 #define AP_PLAN_FORCE_GENERIC 256   /* caller-set in desc[0]: keep the generic LDS engine (tests) */
-#define AP_PLAN_RP 16
 #define AP_PLAN_DESC_INTS 16
 int64_t ap_mel_plan_words(const float *fb_host /*(M,F)*/, int n_mels, int n_bins);
 int ap_mel_plan_host(const float *fb_host /*(M,F)*/, int n_mels, int n_bins,

@@ -167,7 +167,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.n_parts = desc[7];
     W.quads = reinterpret_cast<const float *>(plan + desc[8]);
     W.n_quads = desc[9];
-    W.rowparts = plan + desc[10];
+    W.rowstart = plan + desc[10];
     W.out = P.out_mel;
     W.L = P.L;
     W.T = P.T;
@@ -180,15 +180,17 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.power = P.power;
     int off = APW_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
     W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
-    W.off_pp = off; off += APW_WAVES * APW_PP_STRIDE * (int)sizeof(float);
+    W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
     W.off_wq = off; off += ap_align16(W.n_quads * 16);
     W.off_parts = off; off += ap_align16(W.n_parts * 16);
-    W.off_partial = off; off += ap_align16(W.n_parts * 16);
-    W.off_macc = off; off += ap_align16(M * APW_G * 4);
+    W.off_partial = off; off += ap_align16(APW_WAVES * W.n_parts * 4);
+    W.off_otile = off; off += ap_align16(APW_WAVES * M * APW_G * 4);
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;     // does not fit: caller falls back to the generic engine
-    const int per_cu = off * 2 <= AP_LDS_MAX ? 2 : 1;
-    int64_t g = W.n_tiles < 256 * per_cu ? W.n_tiles : 256 * per_cu;   // persistent workgroups
+    // persistent: one 8-wave workgroup per CU; every wave strides over the tiles on its own
+    int64_t g = (W.n_tiles + APW_WAVES - 1) / APW_WAVES;
+    if (g > 256) g = 256;
     *grid = (int)g;
     return AP_OK;
 }

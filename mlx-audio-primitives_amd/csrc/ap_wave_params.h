@@ -4,25 +4,23 @@
 #include "ap_common.h"
 
 #define APW_NC 1024          // complex points of the packed transform
-#define APW_G 16             // frames per tile (4 rounds of 4 waves)
-#define APW_WAVES 4          // waves (= frames in flight) per workgroup
+#define APW_G 8              // consecutive frames one wave processes before it moves to its next tile
+#define APW_WAVES 8          // waves per workgroup (2 per SIMD; they only share read-only LDS tables)
 #define APW_ROW 18           // padded row (complex) of transpose #1: conflict-free ds_read_b128
 #define APW_X_COMPLEX 1168   // complex slots of one wave's exchange buffer (>= 64*18, >= zidx(1023)+1)
 #define APW_TW2_COMPLEX 72   // 4 rows x 17 (padded) of W_64^(a*c), rounded to 16 bytes
-#define APW_PP_STRIDE 1032   // floats per |X|^p plane (1025 bins, padded to a 16-byte multiple)
-#define APW_RP 16            // max parts per filter row (== AP_PLAN_RP)
 
 struct ApMelWaveParams {
     const float *y;            // (B, L)
     const float *window;       // (2048)
     const ap_float2 *tw;       // (2048) (cos, sin)(2 pi j / 2048)
-    const int32_t *parts;      // (n_parts, 4): row, first group, n_groups, first quad
+    const int32_t *parts;      // (n_parts, 4): slot, first group, n_groups, first quad
     const float *quads;        // (n_quads, 4) filter weights of the 4 bins of a group
-    const int32_t *rowparts;   // (M, APW_RP) part ids per row, -1 padded
+    const int32_t *rowstart;   // (M+1) slot range of every row
     float *out;                // (B, M, T)
     int64_t L, T, tiles_per_clip, n_tiles;
     int hop, pad, pad_mode, n_mels, n_parts, n_quads;
     float power;
     // LDS carve-up (bytes from the start of dynamic LDS)
-    int off_tw2, off_pp, off_wq, off_parts, off_partial, off_macc, lds_bytes;
+    int off_tw2, off_tw1, off_win, off_wq, off_parts, off_partial, off_otile, lds_bytes;
 };

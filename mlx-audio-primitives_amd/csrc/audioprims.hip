@@ -34,13 +34,20 @@ static int ap_allow_lds(K kernel, int bytes) {
     return AP_OK;
 }
 
-template <int PMODE>
+template <int PMODE, int PADGEN>
 static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) {
-    int rc = ap_allow_lds(ap_mel2048_wave_kernel<PMODE>, W.lds_bytes);
+    int rc = ap_allow_lds(ap_mel2048_wave_kernel<PMODE, PADGEN>, W.lds_bytes);
     if (rc != AP_OK) return rc;
-    hipLaunchKernelGGL(ap_mel2048_wave_kernel<PMODE>, dim3(grid), dim3(256), W.lds_bytes,
+    hipLaunchKernelGGL((ap_mel2048_wave_kernel<PMODE, PADGEN>), dim3(grid), dim3(64 * APW_WAVES), W.lds_bytes,
                        (hipStream_t)stream, W);
     return ap_check_launch("ap_melspec_f32(wave)");
+}
+
+template <int PADGEN>
+static int ap_launch_mel_wave_p(const ApMelWaveParams &W, int grid, float power, void *stream) {
+    if (power == 2.0f) return ap_launch_mel_wave<2, PADGEN>(W, grid, stream);
+    if (power == 1.0f) return ap_launch_mel_wave<1, PADGEN>(W, grid, stream);
+    return ap_launch_mel_wave<0, PADGEN>(W, grid, stream);
 }
 
 extern "C" {
@@ -108,9 +115,10 @@ int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, con
         ApMelWaveParams W;
         int grid = 0;
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
-            if (power == 2.0f) return ap_launch_mel_wave<2>(W, grid, stream);
-            if (power == 1.0f) return ap_launch_mel_wave<1>(W, grid, stream);
-            return ap_launch_mel_wave<0>(W, grid, stream);
+            // constant padding (or no centring) needs no index remap: bounds-checked buffer loads
+            if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
+                return ap_launch_mel_wave_p<0>(W, grid, power, stream);
+            return ap_launch_mel_wave_p<1>(W, grid, power, stream);
         }
     }
     rc = ap_allow_lds(ap_stft_generic_kernel<1>, P.tile.lds_bytes);

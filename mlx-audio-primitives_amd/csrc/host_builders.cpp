@@ -173,7 +173,7 @@ int ap_twiddle_table_host(int n_fft, float *out_host) {
 }
 
 namespace {
-struct MelPart { int row, g0, ng, q0; };
+struct MelPart { int row, g0, ng, q0, slot; };
 
 // spans + parts of a dense filterbank; returns total quads
 void mel_analyse(const float *fb, int M, int F, std::vector<int> &lo, std::vector<int> &len,
@@ -196,6 +196,7 @@ void mel_analyse(const float *fb, int M, int F, std::vector<int> &lo, std::vecto
             p.g0 = g;
             p.ng = (glast - g + 1) < 4 ? (glast - g + 1) : 4;
             p.q0 = 0;
+            p.slot = (int)parts.size();       // row-major position: a row's parts are adjacent
             parts.push_back(p);
         }
     }
@@ -214,8 +215,7 @@ int64_t ap_mel_plan_words(const float *fb, int n_mels, int n_bins) {
     mel_analyse(fb, n_mels, n_bins, lo, len, parts);
     int64_t quads = 0;
     for (auto &p : parts) quads += p.ng;
-    return 2 * (int64_t)n_mels + 4 * (int64_t)parts.size() + 4 * quads +
-           (int64_t)n_mels * AP_PLAN_RP + 8;
+    return 2 * (int64_t)n_mels + 4 * (int64_t)parts.size() + 4 * quads + (int64_t)n_mels + 1 + 8;
 }
 
 int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int32_t *desc) {
@@ -238,15 +238,21 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     off += off & 3 ? 4 - (off & 3) : 0;                       // 16-byte align the int4 / float4 tables
     const int64_t off_parts = off; off += 4 * (int64_t)parts.size();
     const int64_t off_quads = off; off += 4 * quads;
-    const int64_t off_rp = off; off += (int64_t)M * AP_PLAN_RP;
+    const int64_t off_rs = off; off += (int64_t)M + 1;
     for (int m = 0; m < M; ++m) { plan[off_lo + m] = lo[m]; plan[off_len + m] = len[m]; }
     bool parts_ok = true;
-    std::vector<int> nrp(M, 0);
-    for (int64_t i = 0; i < M * (int64_t)AP_PLAN_RP; ++i) plan[off_rp + i] = -1;
+    // rowstart[m] .. rowstart[m+1]: the row-major slots that hold row m's partial sums
+    {
+        std::vector<int> cnt(M, 0);
+        for (auto &p : parts) cnt[p.row]++;
+        int acc = 0;
+        for (int m = 0; m < M; ++m) { plan[off_rs + m] = acc; acc += cnt[m]; }
+        plan[off_rs + M] = acc;
+    }
     float *wq = reinterpret_cast<float *>(plan + off_quads);
     for (size_t i = 0; i < parts.size(); ++i) {
         const MelPart &p = parts[i];
-        plan[off_parts + 4 * i + 0] = p.row;
+        plan[off_parts + 4 * i + 0] = p.slot;
         plan[off_parts + 4 * i + 1] = p.g0;
         plan[off_parts + 4 * i + 2] = p.ng;
         plan[off_parts + 4 * i + 3] = p.q0;
@@ -255,9 +261,6 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
                 const int k = 4 * (p.g0 + g) + e;
                 wq[4 * (size_t)(p.q0 + g) + e] = k < F ? fb[(size_t)p.row * F + k] : 0.0f;
             }
-        if (nrp[p.row] < AP_PLAN_RP) plan[off_rp + (int64_t)p.row * AP_PLAN_RP + nrp[p.row]] = (int)i;
-        else parts_ok = false;
-        nrp[p.row]++;
     }
     desc[0] = AP_PLAN_BANDED | (parts_ok ? AP_PLAN_PARTS : 0);
     desc[1] = M;
@@ -269,8 +272,8 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     desc[7] = (int32_t)parts.size();
     desc[8] = (int32_t)off_quads;
     desc[9] = (int32_t)quads;
-    desc[10] = (int32_t)off_rp;
-    desc[11] = AP_PLAN_RP;
+    desc[10] = (int32_t)off_rs;
+    desc[11] = 0;
     return AP_OK;
 }
 

@@ -1,8 +1,8 @@
 // Fused mel-spectrogram kernel for n_fft = 2048 on gfx950: one wavefront per frame.
 //
-// A 256-thread workgroup (4 wave64) owns a tile of 16 consecutive frames of one clip
-// and walks it in 4 rounds; in a round every wave transforms ONE frame entirely in its
-// own registers + a wave-private LDS exchange buffer (no s_barrier inside the FFT):
+// Every wave64 is an independent worker: it takes tiles of 8 consecutive frames of one clip
+// and transforms ONE frame at a time entirely in its own registers + a wave-private LDS
+// exchange buffer (no s_barrier anywhere in the frame loop):
 //
 //   global samples (16 x 8 B per lane, prefetched one round ahead) * window (registers)
 //   radix-16 butterflies in registers                              [mx.fft.rfft, stft.py:130]
@@ -12,19 +12,24 @@
 //   LDS transpose #2 to natural order -> paired real-input split (bins k and 1024-k
 //   share their sums) -> |X|^p -> one float plane per wave in LDS
 //
-// then, once per round, the workgroup contracts the 4 planes with the mel filterbank
-// (mx.matmul(mel_basis, S), mel.py:344-350) from a host-built plan: every filter's span
-// is cut into parts of <= 4 aligned 4-bin groups; a thread owns (part, frame), does one
-// ds_read_b128 of weights + one of |X|^p per group, and the <= 16 partial sums of a row are
-// added by the thread that owns (row, frame).  No atomics (LDS float atomics cost ~3
-// cycles per lane on gfx950 and made the first version of this kernel LDS-bound).
-// After 4 rounds the (n_mels x 16) tile goes to HBM as 64-byte row segments of (B,M,T).
+// then the same wave contracts its plane with the mel filterbank (mx.matmul(mel_basis, S),
+// mel.py:344-350) from a host-built plan: every filter's span is cut into parts of <= 4
+// aligned 4-bin groups, sorted by length; a lane owns a part, does one ds_read_b128 of
+// weights + one of |X|^p per group, and the partial sums of a row (adjacent slots) are added
+// by the lane that owns the row and stored as one column of (B,M,T).  No atomics (LDS float
+// atomics cost ~3 cycles per lane on gfx950 and made the first version of this kernel
+// LDS-bound) and no workgroup barrier after the table set-up: the 12 waves of a workgroup
+// only share the read-only tables (window, twiddles, filter weights) in LDS.
 //
 // The complex 1024-point transform is 16 x 16 x 4.  Workgroups are persistent over tiles.
 #pragma once
 #include "ap_wave_params.h"
 #include "fft_lds.h"
 #include "kernels_generic.h"
+
+// cos/sin(2 pi r / 32), r = 0..7, as compile-time constants (W_2048^(64 r) = W_32^r)
+#define APW_C32(r) ((float)__builtin_cos(6.283185307179586476925 * (r) / 32.0))
+#define APW_S32(r) ((float)__builtin_sin(6.283185307179586476925 * (r) / 32.0))
 
 #ifdef AP_HOST_EMU
 #define AP_WAVE_SYNC() emu_wave_sync()
@@ -66,38 +71,58 @@ AP_DEV float apw_pow2x(float re, float im, float power) {
     return powf(0.5f * sqrtf(p2), power);
 }
 
-template <int PMODE>
-__global__ void __launch_bounds__(256, 2) ap_mel2048_wave_kernel(ApMelWaveParams P) {
+#ifdef AP_HOST_EMU
+#define AP_UNIFORM(x) (x)
+// one clip as a bounds-checked buffer: out-of-range samples read as 0 (= constant padding)
+struct ApClip { const float *base; int64_t n; };
+AP_DEV ApClip ap_clip_make(const float *base, int64_t n) { ApClip c; c.base = base; c.n = n; return c; }
+AP_DEV float ap_clip_load(const ApClip &c, int64_t idx) { return (idx >= 0 && idx < c.n) ? c.base[idx] : 0.0f; }
+#else
+#define AP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler x is wave-uniform
+// one clip as a raw buffer resource: the hardware range check returns 0 for every sample
+// outside [0, L) — constant padding (stft.py:441-442) with no branch and 32-bit offsets
+typedef __amdgpu_buffer_rsrc_t ApClip;
+AP_DEV ApClip ap_clip_make(const float *base, int64_t n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(n * 4), 0x00020000);
+}
+AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
+    // a negative index wraps to a huge unsigned byte offset: out of range -> 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c, (int)(idx * 4), 0, 0));
+}
+#endif
+
+// PADGEN = 0: constant padding (or none) through the bounds-checked clip buffer;
+// PADGEN = 1: edge / reflect padding through the per-sample remap of kernels_generic.h
+template <int PMODE, int PADGEN>
+__global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMelWaveParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = AP_UNIFORM(tid >> 6);
     ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
-    ap_float2 *TW2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);     // [4][17]
-    float *PP = reinterpret_cast<float *>(ap_smem + P.off_pp);               // [4][APW_PP_STRIDE]
-    ap_float4 *WQ = reinterpret_cast<ap_float4 *>(ap_smem + P.off_wq);       // [n_quads]
-    ap_int4 *PART = reinterpret_cast<ap_int4 *>(ap_smem + P.off_parts);      // [n_parts]
-    float *PARTIAL = reinterpret_cast<float *>(ap_smem + P.off_partial);     // [n_parts][4]
-    float *MACC = reinterpret_cast<float *>(ap_smem + P.off_macc);           // [M][16]
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);   // [4][17]
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);   // [16][64]
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // [1024] pairs
+    const ap_float4 *WQ = reinterpret_cast<const ap_float4 *>(ap_smem + P.off_wq);     // [n_quads]
+    const ap_int4 *PART = reinterpret_cast<const ap_int4 *>(ap_smem + P.off_parts);    // [n_parts]
+    float *partial = reinterpret_cast<float *>(ap_smem + P.off_partial) + wave * P.n_parts;   // this wave's
+    float *otile = reinterpret_cast<float *>(ap_smem + P.off_otile) + wave * P.n_mels * APW_G;  // [M][APW_G]
     const int M = P.n_mels;
 
-    // ---------------- workgroup tables (once) ---------------------------------------
-    for (int i = tid; i < P.n_quads; i += 256)
-        WQ[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
-    for (int i = tid; i < P.n_parts; i += 256)
-        PART[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
-    if (tid < 64) TW2[(tid >> 4) * 17 + (tid & 15)] = P.tw[32 * (tid >> 4) * (tid & 15)];   // W_64^(a*c)
-    // ---------------- per-lane constants (registers) --------------------------------
-    float win[32];
-    ap_float2 tw1[16], tws[8];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        win[2 * j] = P.window[2 * (lane + 64 * j)];
-        win[2 * j + 1] = P.window[2 * (lane + 64 * j) + 1];
-        tw1[j] = P.tw[2 * lane * j];                 // W_1024^(lane*j)
+    // ---------------- workgroup tables in LDS (once; the only workgroup barrier) ------
+    {
+        const int nt = 64 * APW_WAVES;
+        ap_float4 *wq = reinterpret_cast<ap_float4 *>(ap_smem + P.off_wq);
+        ap_int4 *part = reinterpret_cast<ap_int4 *>(ap_smem + P.off_parts);
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        ap_float2 *win = reinterpret_cast<ap_float2 *>(ap_smem + P.off_win);
+        for (int i = tid; i < P.n_quads; i += nt) wq[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
+        for (int i = tid; i < P.n_parts; i += nt) part[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
+        if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = P.tw[32 * (tid >> 4) * (tid & 15)];   // W_64^(a*c)
+        for (int i = tid; i < 16 * 64; i += nt) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];         // W_1024^(lane*k1)
+        for (int i = tid; i < APW_NC; i += nt) win[i] = reinterpret_cast<const ap_float2 *>(P.window)[i];
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) tws[r] = P.tw[lane + 64 * r];    // W_2048^k, k = lane + 64 r
-    // rows this thread sums in the gather pass: (row, frame) = (v >> 2, v & 3), v = tid + 256 i
+    const ap_float2 tws0 = P.tw[lane];               // W_2048^lane; bins k = lane + 64 r add W_32^r
     const int qa = lane & 3;                         // position in the quad
     const float s1 = qa < 2 ? 1.0f : -1.0f;          // radix-4 stage-1 sign
     const float s2 = (qa & 1) ? -1.0f : 1.0f;        // radix-4 stage-2 sign
@@ -105,129 +130,157 @@ __global__ void __launch_bounds__(256, 2) ap_mel2048_wave_kernel(ApMelWaveParams
     const int qd = ((qa & 1) << 1) | (qa >> 1);      // output digit held by this lane
     const int k1p = lane >> 2;
     const ap_float2 *tw2row = TW2 + qa * 17;
-    float *pp = PP + wave * APW_PP_STRIDE;
+    float *pp = reinterpret_cast<float *>(X);        // |X|^p plane of this wave, aliased on its X buffer
     __syncthreads();
 
-    for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    // every wave is an independent worker over (clip, APW_G-frame tile) units
+    // adjacent waves take adjacent tiles: their overlapping samples and the neighbouring
+    // 32-byte output segments then meet in the same L1 / L2
+    const int64_t worker = (int64_t)blockIdx.x * APW_WAVES + wave;
+    const int64_t n_workers = (int64_t)gridDim.x * APW_WAVES;
+    ap_float2 raw[16];
+    auto load_frame = [&](int64_t tile, int g) {
+        const int64_t b = tile / P.tiles_per_clip;
+        const int64_t t = (tile - b * P.tiles_per_clip) * APW_G + g;
+        const float *yb = P.y + b * P.L;
+        const ApClip clip = ap_clip_make(yb, P.L);
+        const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t p = base + 2 * (lane + 64 * j);
+            if (PADGEN)
+                raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode),
+                               ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            else
+                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+        }
+    };
+    if (worker < P.n_tiles) load_frame(worker, 0);
+
+    for (int64_t tile = worker; tile < P.n_tiles; tile += n_workers) {
         const int64_t b = tile / P.tiles_per_clip;
         const int64_t t0 = (tile - b * P.tiles_per_clip) * APW_G;
         const int Gt = (int)((P.T - t0) < APW_G ? (P.T - t0) : APW_G);
-        const float *yb = P.y + b * P.L;
-
-        ap_float2 raw[16];
-        auto load_frame = [&](int g) {
-            const int64_t base = (t0 + g) * (int64_t)P.hop - P.pad;
-            if (base >= 0 && base + 2 * APW_NC <= P.L) {
-                const float *src = yb + base;
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    raw[j] = ap_mk(src[2 * lane + 128 * j], src[2 * lane + 128 * j + 1]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int64_t p = base + 2 * (lane + 64 * j);
-                    raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode),
-                                   ap_load_padded(yb, P.L, p + 1, P.pad_mode));
-                }
-            }
-        };
-        if (wave < Gt) load_frame(wave);
-
-        for (int round = 0; round < APW_G / APW_WAVES; ++round) {
-            const int g = round * APW_WAVES + wave;          // this wave's frame in the tile
-            if (g < Gt) {
-                ap_float2 v[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ap_mk(raw[j].x * win[2 * j], raw[j].y * win[2 * j + 1]);
-                if (g + APW_WAVES < Gt) load_frame(g + APW_WAVES);   // in flight during this frame
-                // ---- pass 1: radix-16 over j, twiddle W_1024^(lane*k1) -----------------
-                ApButterfly<16>::run(v);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], tw1[k]);
-                // ---- transpose #1: (n0 = a + 4b, k1) -> lane (k1, a), register b -------
-                {
-                    const int a = lane & 3, bq = lane >> 2;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) X[(k * 4 + a) * APW_ROW + bq] = v[k];
-                }
-                AP_WAVE_SYNC();
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = X[lane * APW_ROW + i];
-                AP_WAVE_SYNC();
-                // ---- pass 2: radix-16 over b, twiddle W_64^(a*c) from the LDS table ------
-                ApButterfly<16>::run(v);
-#pragma unroll
-                for (int c = 1; c < 16; ++c) v[c] = ap_mul_fw(v[c], tw2row[c]);
-                // ---- pass 3: radix-4 across the quad (DIF), outputs in bit-reversed lanes -
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    float tx = ap_quad_xor2(v[c].x) + s1 * v[c].x;
-                    float ty = ap_quad_xor2(v[c].y) + s1 * v[c].y;
-                    const float rx = rot ? ty : tx;          // * (-i) on lane 3
-                    const float ry = rot ? -tx : ty;
-                    v[c].x = ap_quad_xor1(rx) + s2 * rx;
-                    v[c].y = ap_quad_xor1(ry) + s2 * ry;
-                }
-                // ---- transpose #2: natural order Z[k], k = k1 + 16 c + 256 d ------------
-#pragma unroll
-                for (int c = 0; c < 16; ++c) X[apw_zidx(k1p + 16 * c + 256 * qd)] = v[c];
-                AP_WAVE_SYNC();
-                // ---- paired real split: bins k = lane + 64 r and 1024 - k ----------------
-                //   a2 = Z[k] + conj Z[1024-k], d2 = Z[k] - conj Z[1024-k], u = W^k d2
-                //   2X[k] = (a2.x + u.y, a2.y - u.x),  2X[1024-k] = (a2.x - u.y, -a2.y - u.x)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int k = lane + 64 * r;
-                    const ap_float2 zk = X[apw_zidx(k)];
-                    const ap_float2 zm = X[apw_zidx((APW_NC - k) & (APW_NC - 1))];
-                    const float ax = zk.x + zm.x, ay = zk.y - zm.y;
-                    const float dx = zk.x - zm.x, dy = zk.y + zm.y;
-                    const float ux = tws[r].x * dx + tws[r].y * dy;
-                    const float uy = tws[r].x * dy - tws[r].y * dx;
-                    pp[k] = apw_pow2x<PMODE>(ax + uy, ay - ux, P.power);
-                    pp[APW_NC - k] = apw_pow2x<PMODE>(ax - uy, -ay - ux, P.power);
-                }
-                if (lane == 0) {                                   // the unpaired bin 512
-                    const ap_float2 zh = X[apw_zidx(APW_NC / 2)];
-                    pp[APW_NC / 2] = apw_pow2x<PMODE>(2.0f * zh.x, 2.0f * zh.y, P.power);
-                }
-            }
-            __syncthreads();
-            // ---- mel contraction of the 4 planes of this round -------------------------
-            for (int u = tid; u < 4 * P.n_parts; u += 256) {
-                const ap_int4 pd = PART[u >> 2];                   // row, g0, ng, q0
-                const int f = u & 3;
-                const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(PP + f * APW_PP_STRIDE) + pd.y;
-                const ap_float4 *wq = WQ + pd.w;
-                float acc = 0.0f;
-                for (int i = 0; i < pd.z; ++i) {
-                    const ap_float4 w = wq[i], p = pq[i];
-                    acc = fmaf(w.x, p.x, acc);
-                    acc = fmaf(w.y, p.y, acc);
-                    acc = fmaf(w.z, p.z, acc);
-                    acc = fmaf(w.w, p.w, acc);
-                }
-                PARTIAL[u] = acc;
-            }
-            __syncthreads();
-            for (int vv = tid; vv < 4 * M; vv += 256) {
-                const int row = vv >> 2, f = vv & 3;
-                const int32_t *rp = P.rowparts + row * APW_RP;
-                float sum = 0.0f;
-                for (int j = 0; j < APW_RP; ++j) {
-                    const int pid = rp[j];
-                    if (pid < 0) break;
-                    sum += PARTIAL[pid * 4 + f];
-                }
-                MACC[row * APW_G + round * APW_WAVES + f] = sum;
-            }
-        }
-        __syncthreads();
-        // ---- store the tile: 16 consecutive lanes write one 64-byte row segment -----
         float *ob = P.out + b * (int64_t)M * P.T + t0;
-        for (int e = tid; e < M * APW_G; e += 256) {
-            const int m = e >> 4, g = e & 15;
-            if (g < Gt) ob[(int64_t)m * P.T + g] = MACC[e];
+
+        for (int g = 0; g < Gt; ++g) {
+            ap_float2 v[16];
+            {
+                ap_float2 w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = ap_mk(raw[j].x * w[j].x, raw[j].y * w[j].y);
+            }
+            // issue the next frame's loads only AFTER the old samples are consumed: otherwise the
+            // compiler hoists them and then has to wait vmcnt(0) for them inside this frame
+            AP_SCHED_FENCE();
+            if (g + 1 < Gt) load_frame(tile, g + 1);                 // in flight during this frame
+            else if (tile + n_workers < P.n_tiles) load_frame(tile + n_workers, 0);
+            AP_SCHED_FENCE();
+            // ---- pass 1: radix-16 over j, twiddle W_1024^(lane*k1) -----------------
+            {
+                ap_float2 t1[16];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];   // lands during the butterfly
+                ApButterfly<16>::run(v);
+#pragma unroll
+                for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
+            }
+            // ---- transpose #1: (n0 = a + 4b, k1) -> lane (k1, a), register b -------
+            {
+                const int a = lane & 3, bq = lane >> 2;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) X[(k * 4 + a) * APW_ROW + bq] = v[k];
+            }
+            AP_WAVE_SYNC();
+            ap_float2 t2[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = X[lane * APW_ROW + i];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) t2[c] = tw2row[c];                // W_64^(a*c)
+            AP_WAVE_SYNC();
+            // ---- pass 2: radix-16 over b, twiddle W_64^(a*c) -------------------------
+            ApButterfly<16>::run(v);
+#pragma unroll
+            for (int c = 1; c < 16; ++c) v[c] = ap_mul_fw(v[c], t2[c]);
+            // ---- pass 3: radix-4 across the quad (DIF), outputs in bit-reversed lanes -
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float tx = ap_quad_xor2(v[c].x) + s1 * v[c].x;
+                float ty = ap_quad_xor2(v[c].y) + s1 * v[c].y;
+                const float rx = rot ? ty : tx;          // * (-i) on lane 3
+                const float ry = rot ? -tx : ty;
+                v[c].x = ap_quad_xor1(rx) + s2 * rx;
+                v[c].y = ap_quad_xor1(ry) + s2 * ry;
+            }
+            // ---- transpose #2: natural order Z[k], k = k1 + 16 c + 256 d ------------
+#pragma unroll
+            for (int c = 0; c < 16; ++c) X[apw_zidx(k1p + 16 * c + 256 * qd)] = v[c];
+            AP_WAVE_SYNC();
+            // ---- paired real split: bins k = lane + 64 r and 1024 - k ----------------
+            //   a2 = Z[k] + conj Z[1024-k], d2 = Z[k] - conj Z[1024-k], u = W^k d2
+            //   2X[k] = (a2.x + u.y, a2.y - u.x),  2X[1024-k] = (a2.x - u.y, -a2.y - u.x)
+            // every Z value is read into registers first: the plane of |X|^p overwrites Z
+            ap_float2 zk[8], zm[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                zk[r] = X[apw_zidx(k)];
+                zm[r] = X[apw_zidx((APW_NC - k) & (APW_NC - 1))];
+            }
+            const ap_float2 zh = X[apw_zidx(APW_NC / 2)];
+            AP_WAVE_SYNC();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                const float ax = zk[r].x + zm[r].x, ay = zk[r].y - zm[r].y;
+                const float dx = zk[r].x - zm[r].x, dy = zk[r].y + zm[r].y;
+                // (cos, sin) of angle(lane) + angle(64 r): angle addition with constants
+                const float wc = tws0.x * APW_C32(r) - tws0.y * APW_S32(r);
+                const float ws = tws0.y * APW_C32(r) + tws0.x * APW_S32(r);
+                const float ux = wc * dx + ws * dy;
+                const float uy = wc * dy - ws * dx;
+                pp[k] = apw_pow2x<PMODE>(ax + uy, ay - ux, P.power);
+                pp[APW_NC - k] = apw_pow2x<PMODE>(ax - uy, -ay - ux, P.power);
+            }
+            if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(2.0f * zh.x, 2.0f * zh.y, P.power);
+            AP_WAVE_SYNC();
+            // ---- mel contraction of this frame by its own wave (no workgroup barrier) ----
+            // parts are sorted by length, so the 64 lanes of one pass run loops of ~equal length
+            for (int p0 = 0; p0 < P.n_parts; p0 += 64) {
+                const int pi = p0 + lane;
+                if (pi < P.n_parts) {
+                    const ap_int4 pd = PART[pi];                   // slot, g0, ng, q0
+                    const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                    const ap_float4 *wq = WQ + pd.w;
+                    float acc = 0.0f;
+                    for (int i = 0; i < pd.z; ++i) {
+                        const ap_float4 w = wq[i], q = pq[i];
+                        acc = fmaf(w.x, q.x, acc);
+                        acc = fmaf(w.y, q.y, acc);
+                        acc = fmaf(w.z, q.z, acc);
+                        acc = fmaf(w.w, q.w, acc);
+                    }
+                    partial[pd.x] = acc;
+                }
+            }
+            AP_WAVE_SYNC();
+            // a row's partial sums are adjacent; frame t0+g is one column of this wave's
+            // (M x APW_G) output tile
+            for (int row = lane; row < M; row += 64) {
+                const int a0 = P.rowstart[row], a1 = P.rowstart[row + 1];
+                float sum = 0.0f;
+                for (int j = a0; j < a1; ++j) sum += partial[j];
+                otile[row * APW_G + g] = sum;
+            }
+            AP_WAVE_SYNC();
         }
+        // ---- store the tile: APW_G consecutive lanes write one 32-byte row segment of (B,M,T) --
+        for (int e = lane; e < M * APW_G; e += 64) {
+            const int m = e / APW_G, g = e - m * APW_G;
+            if (g < Gt) ob[(int64_t)m * P.T + g] = otile[e];
+        }
+        AP_WAVE_SYNC();
     }
 }

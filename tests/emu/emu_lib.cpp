@@ -69,10 +69,14 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         ApMelWaveParams W;
         int grid = 0;
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
-            if (grid > 3) grid = 3;   // exercise the persistent tile loop
-            if (power == 2.0f) emu_launch((unsigned)grid, 256, [&] { ap_mel2048_wave_kernel<2>(W); });
-            else if (power == 1.0f) emu_launch((unsigned)grid, 256, [&] { ap_mel2048_wave_kernel<1>(W); });
-            else emu_launch((unsigned)grid, 256, [&] { ap_mel2048_wave_kernel<0>(W); });
+            if (grid > 1) grid = 1;   // exercise the persistent tile loop
+            const bool gen = !(W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT);
+            if (power == 2.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 0>(W); });
+            else if (power == 2.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 1>(W); });
+            else if (power == 1.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 0>(W); });
+            else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 1>(W); });
+            else if (!gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 0>(W); });
+            else emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 1>(W); });
             return AP_OK;
         }
     }
