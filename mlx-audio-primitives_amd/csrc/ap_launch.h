@@ -84,6 +84,18 @@ static inline int ap_prepare_resample_poly(const float *x, int64_t B, int64_t L,
     return AP_OK;
 }
 
+// LDS-tiled decimator (up == 1): eligibility and dynamic LDS size
+static inline bool ap_resample_decim_eligible(int up, int down, int n_taps, int *lds_bytes) {
+    if (up != 1 || down < 2 || down > 8) return false;
+    const int R = 4;
+    const int margin = down * (R - 1);
+    const int n_h = (n_taps + 2 * margin + 3) & ~3;
+    const int span = AP_BLOCK * R * down + n_taps - 1;
+    const int xs = span + (span >> 5) + 1;
+    *lds_bytes = (n_h + xs) * (int)sizeof(float);
+    return *lds_bytes <= 64 * 1024;
+}
+
 static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, int64_t L, int n_fft,
                                   int hop, const float *window, const float *tw, int center,
                                   int pad_mode, int64_t T) {

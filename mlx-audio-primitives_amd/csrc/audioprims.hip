@@ -154,6 +154,18 @@ int ap_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down,
     int64_t bpr;
     int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
     if (rc != AP_OK) return rc;
+    int lds = 0;
+    if (ap_resample_decim_eligible(up, down, n_taps, &lds)) {
+        const int64_t per_block = AP_BLOCK * 4;
+        const int64_t bpr4 = (n_out + per_block - 1) / per_block;
+        if (bpr4 * B <= kApMaxGrid) {
+            rc = ap_allow_lds(ap_resample_decim_kernel, lds);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(ap_resample_decim_kernel, dim3((unsigned)(bpr4 * B)), dim3(AP_BLOCK), lds,
+                               (hipStream_t)stream, x, L, down, taps, n_taps, n_pre_remove, n_out, bpr4, out);
+            return ap_check_launch("ap_resample_poly_f32(decim)");
+        }
+    }
     hipLaunchKernelGGL(ap_resample_poly_kernel, dim3((unsigned)(bpr * B)), dim3(AP_BLOCK), 0,
                        (hipStream_t)stream, x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
     return ap_check_launch("ap_resample_poly_f32");

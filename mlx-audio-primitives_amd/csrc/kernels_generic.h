@@ -259,6 +259,64 @@ ap_resample_poly_kernel(const float *x, int64_t L, int up, int down, const float
     out[b * n_out + o] = acc;
 }
 
+// Decimating case (up == 1, e.g. 48 kHz -> 16 kHz) of the same filter, LDS-tiled and register
+// blocked: a workgroup stages the contiguous input span of 256*R outputs once (coalesced,
+// zeros outside the clip = SciPy's zero padding) and every thread slides over the span
+// accumulating R consecutive outputs, so each staged sample is read from LDS once per thread
+// instead of n_taps/down times from L1.  Taps are wave-uniform per step.  Same products, same
+// increasing-input-index order and no FMA contraction: still bit-exact against SciPy.
+#define AP_RSP_R 4
+AP_DEV int ap_rsp_pad(int a) { return a + (a >> 5); }   // break the R*down lane stride across banks
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps, int n_taps,
+                         int n_pre_remove, int64_t n_out, int64_t blocks_per_row, float *out) {
+#ifndef AP_HOST_EMU
+#pragma clang fp contract(off)
+#endif
+    const int tid = threadIdx.x;
+    const int R = AP_RSP_R;
+    const int margin = down * (R - 1);
+    const int n_h = n_taps + 2 * margin;                    // taps zero-padded by `margin` each side
+    float *hs = reinterpret_cast<float *>(ap_smem);
+    float *xs = hs + ((n_h + 3) & ~3);
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / blocks_per_row;
+    const int64_t o0 = (bid - b * blocks_per_row) * (AP_BLOCK * R);
+    const int span = AP_BLOCK * R * down + n_taps - 1;      // input samples this workgroup touches
+    const int64_t s0 = (o0 + n_pre_remove) * (int64_t)down - (n_taps - 1);   // first of them (may be < 0)
+    const float *xb = x + b * L;
+    for (int i = tid; i < n_h; i += AP_BLOCK) {
+        const int j = i - margin;
+        hs[i] = (j >= 0 && j < n_taps) ? taps[j] : 0.0f;
+    }
+    for (int i = tid; i < span; i += AP_BLOCK) {
+        const int64_t g = s0 + i;
+        xs[ap_rsp_pad(i)] = (g >= 0 && g < L) ? xb[g] : 0.0f;
+    }
+    __syncthreads();
+    // thread -> outputs o0 + R*tid + r; its window starts at xs[R*down*tid]
+    float acc[AP_RSP_R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+    const int xbase = R * down * tid;
+    const int steps = n_taps + margin;                      // d = 0 .. n_taps-1+margin
+    for (int d = 0; d < steps; ++d) {
+        const float xv = xs[ap_rsp_pad(xbase + d)];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            // output r sees this sample through tap (n_taps-1) - d + down*r (zero outside the filter)
+            const float h = hs[(n_taps - 1) - d + down * r + margin];
+            acc[r] = acc[r] + h * xv;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t o = o0 + (int64_t)R * tid + r;
+        if (o < n_out) out[b * n_out + o] = acc[r];
+    }
+}
+
 // reference resample.py:183-195: float64 positions and interpolation, float32 result
 __global__ void __launch_bounds__(AP_BLOCK)
 ap_resample_linear_kernel(const float *x, int64_t B, int64_t L, int64_t n_out, double scale, float *out) {

@@ -98,6 +98,14 @@ int emu_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down
     int64_t bpr;
     int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
     if (rc != AP_OK) return rc;
+    int lds = 0;
+    if (ap_resample_decim_eligible(up, down, n_taps, &lds)) {
+        const int64_t bpr4 = (n_out + AP_BLOCK * 4 - 1) / (AP_BLOCK * 4);
+        emu_launch((unsigned)(bpr4 * B), AP_BLOCK, [&] {
+            ap_resample_decim_kernel(x, L, down, taps, n_taps, n_pre_remove, n_out, bpr4, out);
+        });
+        return AP_OK;
+    }
     emu_launch((unsigned)(bpr * B), AP_BLOCK, [&] {
         ap_resample_poly_kernel(x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
     });

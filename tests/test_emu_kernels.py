@@ -141,6 +141,13 @@ def test_emu_resample_poly_bit_exact_vs_scipy():
         want = z[f"{tag}_out"]
         want = want if want.ndim == 2 else want[None]
         np.testing.assert_array_equal(eb.resample_poly(x2, up, down), want)
+    # LDS-tiled decimator (up == 1): ragged lengths, several workgroups, down = 2..5
+    import scipy.signal
+    rng = np.random.default_rng(1)
+    for down, L in ((3, 4800), (2, 5001), (4, 2049), (5, 777), (3, 100)):
+        xx = rng.standard_normal((2, L)).astype(np.float32)
+        np.testing.assert_array_equal(eb.resample_poly(xx, 1, down),
+                                      scipy.signal.resample_poly(xx, 1, down, axis=-1).astype(np.float32))
     x = np.random.default_rng(0).standard_normal((2, 1000)).astype(np.float32)
     np.testing.assert_array_equal(eb.resample_linear(x, 733), ao.resample(x, 1000, 733, res_type="linear"))
     np.testing.assert_allclose(eb.resample_linear(x, 1500, scale=1.5),
