@@ -24,3 +24,18 @@ struct ApMelWaveParams {
     // LDS carve-up (bytes from the start of dynamic LDS)
     int off_tw2, off_tw1, off_win, off_wq, off_parts, off_partial, off_otile, lds_bytes;
 };
+
+// ---- n_fft = 2048 STFT (complex output) wave kernel -----------------------------------
+#define APS_WAVES 8          // waves per workgroup = frames per group (64-byte row segments of (B,F,T))
+#define APS_OB_ROW 9         // complex slots per row of the transpose buffer (8 frames + 1 pad)
+#define APS_OB_ROWS 257      // rows per chunk: 2 x (64 bins + 64 mirrored bins) + bin 512
+
+struct ApStftWaveParams {
+    const float *y;            // (B, L)
+    const float *window;       // (2048)
+    const ap_float2 *tw;       // (2048)
+    ap_float2 *out;            // (B, 1025, T)
+    int64_t L, T, groups_per_clip, n_groups;
+    int hop, pad, pad_mode;
+    int off_tw2, off_tw1, off_win, off_ob, lds_bytes;
+};

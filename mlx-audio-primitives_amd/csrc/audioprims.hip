@@ -95,6 +95,24 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
     if (rc != AP_OK) return rc;
     if (!out) AP_FAIL(AP_ERR_INVALID, "stft: NULL output");
     P.out_c = reinterpret_cast<ap_float2 *>(out);
+    if (n_fft == 2048) {
+        ApStftWaveParams W;
+        int grid = 0;
+        if (ap_prepare_stft_wave(W, P, B, &grid) == AP_OK) {
+            if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT) {
+                rc = ap_allow_lds(ap_stft2048_wave_kernel<0>, W.lds_bytes);
+                if (rc != AP_OK) return rc;
+                hipLaunchKernelGGL(ap_stft2048_wave_kernel<0>, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
+                                   (hipStream_t)stream, W);
+            } else {
+                rc = ap_allow_lds(ap_stft2048_wave_kernel<1>, W.lds_bytes);
+                if (rc != AP_OK) return rc;
+                hipLaunchKernelGGL(ap_stft2048_wave_kernel<1>, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
+                                   (hipStream_t)stream, W);
+            }
+            return ap_check_launch("ap_stft_f32(wave)");
+        }
+    }
     rc = ap_allow_lds(ap_stft_generic_kernel<0>, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(ap_stft_generic_kernel<0>, dim3((unsigned)(P.tiles_per_clip * B)),

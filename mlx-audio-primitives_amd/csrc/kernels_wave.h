@@ -91,6 +91,111 @@ AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
 }
 #endif
 
+
+// per-lane constants of the 1024-point wave transform
+struct ApwLane {
+    int lane, qa, qd, k1p;
+    float s1, s2;
+    bool rot;
+    const ap_float2 *tw2row;
+    ap_float2 tws0;
+};
+
+AP_DEV ApwLane apw_lane_init(int lane, const ap_float2 *TW2, const ap_float2 *tw) {
+    ApwLane c;
+    c.lane = lane;
+    c.qa = lane & 3;                              // position in the quad
+    c.s1 = c.qa < 2 ? 1.0f : -1.0f;               // radix-4 stage-1 sign
+    c.s2 = (c.qa & 1) ? -1.0f : 1.0f;             // radix-4 stage-2 sign
+    c.rot = c.qa == 3;                            // lane 3 multiplies by -i between stages
+    c.qd = ((c.qa & 1) << 1) | (c.qa >> 1);       // output digit held by this lane
+    c.k1p = lane >> 2;
+    c.tw2row = TW2 + c.qa * 17;
+    c.tws0 = tw[lane];                            // W_2048^lane; bins k = lane + 64 r add W_32^r
+    return c;
+}
+
+// workgroup tables: W_64^(a*c) [4][17], W_1024^(lane*k1) [16][64], window as 1024 float pairs
+AP_DEV void apw_fill_tables(ap_float2 *tw2, ap_float2 *tw1, ap_float2 *win, const ap_float2 *tw,
+                            const float *window, int tid, int nt) {
+    if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = tw[32 * (tid >> 4) * (tid & 15)];
+    for (int i = tid; i < 16 * 64; i += nt) tw1[i] = tw[2 * (i & 63) * (i >> 6)];
+    for (int i = tid; i < APW_NC; i += nt) win[i] = reinterpret_cast<const ap_float2 *>(window)[i];
+}
+
+// windowed samples v[j] = z[lane + 64 j]  ->  Z[k] in natural order in the wave's X buffer
+// (slots apw_zidx(k)).  16 x 16 x 4: two in-register radix-16 passes around LDS transpose #1,
+// the radix-4 across the quad with DPP, then LDS transpose #2.
+AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ApwLane &c) {
+    const int lane = c.lane;
+    {
+        ap_float2 t1[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];   // lands during the butterfly
+        ApButterfly<16>::run(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
+    }
+    {   // transpose #1: (n0 = a + 4b, k1) -> lane (k1, a), register b
+        const int a = lane & 3, bq = lane >> 2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) X[(k * 4 + a) * APW_ROW + bq] = v[k];
+    }
+    AP_WAVE_SYNC();
+    ap_float2 t2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = X[lane * APW_ROW + i];
+#pragma unroll
+    for (int cc = 1; cc < 16; ++cc) t2[cc] = c.tw2row[cc];         // W_64^(a*c)
+    AP_WAVE_SYNC();
+    ApButterfly<16>::run(v);
+#pragma unroll
+    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);
+    // radix-4 across the quad (DIF), outputs in bit-reversed lanes
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        float tx = ap_quad_xor2(v[cc].x) + c.s1 * v[cc].x;
+        float ty = ap_quad_xor2(v[cc].y) + c.s1 * v[cc].y;
+        const float rx = c.rot ? ty : tx;          // * (-i) on lane 3
+        const float ry = c.rot ? -tx : ty;
+        v[cc].x = ap_quad_xor1(rx) + c.s2 * rx;
+        v[cc].y = ap_quad_xor1(ry) + c.s2 * ry;
+    }
+    // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) X[apw_zidx(c.k1p + 16 * cc + 256 * c.qd)] = v[cc];
+    AP_WAVE_SYNC();
+}
+
+// paired real split from Z in X: xk[r] = 2 X[lane + 64 r], xm[r] = 2 X[1024 - lane - 64 r],
+// zh = Z[512] (X[512] = conj Z[512]).  All of Z is read before anything else touches X.
+//   a2 = Z[k] + conj Z[1024-k], d2 = Z[k] - conj Z[1024-k], u = W^k d2
+//   2X[k] = (a2.x + u.y, a2.y - u.x),  2X[1024-k] = (a2.x - u.y, -a2.y - u.x)
+AP_DEV void apw_split(const ap_float2 *X, const ApwLane &c, ap_float2 (&xk)[8], ap_float2 (&xm)[8],
+                      ap_float2 &zh) {
+    ap_float2 zk[8], zm[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = c.lane + 64 * r;
+        zk[r] = X[apw_zidx(k)];
+        zm[r] = X[apw_zidx((APW_NC - k) & (APW_NC - 1))];
+    }
+    zh = X[apw_zidx(APW_NC / 2)];
+    AP_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float ax = zk[r].x + zm[r].x, ay = zk[r].y - zm[r].y;
+        const float dx = zk[r].x - zm[r].x, dy = zk[r].y + zm[r].y;
+        // (cos, sin) of angle(lane) + angle(64 r): angle addition with constants
+        const float wc = c.tws0.x * APW_C32(r) - c.tws0.y * APW_S32(r);
+        const float ws = c.tws0.y * APW_C32(r) + c.tws0.x * APW_S32(r);
+        const float ux = wc * dx + ws * dy;
+        const float uy = wc * dy - ws * dx;
+        xk[r] = ap_mk(ax + uy, ay - ux);
+        xm[r] = ap_mk(ax - uy, -ay - ux);
+    }
+}
+
 // PADGEN = 0: constant padding (or none) through the bounds-checked clip buffer;
 // PADGEN = 1: edge / reflect padding through the per-sample remap of kernels_generic.h
 template <int PMODE, int PADGEN>
@@ -113,23 +218,13 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
         const int nt = 64 * APW_WAVES;
         ap_float4 *wq = reinterpret_cast<ap_float4 *>(ap_smem + P.off_wq);
         ap_int4 *part = reinterpret_cast<ap_int4 *>(ap_smem + P.off_parts);
-        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
-        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
-        ap_float2 *win = reinterpret_cast<ap_float2 *>(ap_smem + P.off_win);
         for (int i = tid; i < P.n_quads; i += nt) wq[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
         for (int i = tid; i < P.n_parts; i += nt) part[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
-        if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = P.tw[32 * (tid >> 4) * (tid & 15)];   // W_64^(a*c)
-        for (int i = tid; i < 16 * 64; i += nt) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];         // W_1024^(lane*k1)
-        for (int i = tid; i < APW_NC; i += nt) win[i] = reinterpret_cast<const ap_float2 *>(P.window)[i];
+        apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
+                        reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
+                        reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid, nt);
     }
-    const ap_float2 tws0 = P.tw[lane];               // W_2048^lane; bins k = lane + 64 r add W_32^r
-    const int qa = lane & 3;                         // position in the quad
-    const float s1 = qa < 2 ? 1.0f : -1.0f;          // radix-4 stage-1 sign
-    const float s2 = (qa & 1) ? -1.0f : 1.0f;        // radix-4 stage-2 sign
-    const bool rot = qa == 3;                        // lane 3 multiplies by -i between stages
-    const int qd = ((qa & 1) << 1) | (qa >> 1);      // output digit held by this lane
-    const int k1p = lane >> 2;
-    const ap_float2 *tw2row = TW2 + qa * 17;
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     float *pp = reinterpret_cast<float *>(X);        // |X|^p plane of this wave, aliased on its X buffer
     __syncthreads();
 
@@ -178,73 +273,18 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             if (g + 1 < Gt) load_frame(tile, g + 1);                 // in flight during this frame
             else if (tile + n_workers < P.n_tiles) load_frame(tile + n_workers, 0);
             AP_SCHED_FENCE();
-            // ---- pass 1: radix-16 over j, twiddle W_1024^(lane*k1) -----------------
+            apw_forward(v, X, TW1, lc);
             {
-                ap_float2 t1[16];
+                ap_float2 xk[8], xm[8], zh;
+                apw_split(X, lc, xk, xm, zh);           // all of Z is in registers: the plane overwrites it
 #pragma unroll
-                for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];   // lands during the butterfly
-                ApButterfly<16>::run(v);
-#pragma unroll
-                for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
+                for (int r = 0; r < 8; ++r) {
+                    const int k = lane + 64 * r;
+                    pp[k] = apw_pow2x<PMODE>(xk[r].x, xk[r].y, P.power);
+                    pp[APW_NC - k] = apw_pow2x<PMODE>(xm[r].x, xm[r].y, P.power);
+                }
+                if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(2.0f * zh.x, 2.0f * zh.y, P.power);
             }
-            // ---- transpose #1: (n0 = a + 4b, k1) -> lane (k1, a), register b -------
-            {
-                const int a = lane & 3, bq = lane >> 2;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) X[(k * 4 + a) * APW_ROW + bq] = v[k];
-            }
-            AP_WAVE_SYNC();
-            ap_float2 t2[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = X[lane * APW_ROW + i];
-#pragma unroll
-            for (int c = 1; c < 16; ++c) t2[c] = tw2row[c];                // W_64^(a*c)
-            AP_WAVE_SYNC();
-            // ---- pass 2: radix-16 over b, twiddle W_64^(a*c) -------------------------
-            ApButterfly<16>::run(v);
-#pragma unroll
-            for (int c = 1; c < 16; ++c) v[c] = ap_mul_fw(v[c], t2[c]);
-            // ---- pass 3: radix-4 across the quad (DIF), outputs in bit-reversed lanes -
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                float tx = ap_quad_xor2(v[c].x) + s1 * v[c].x;
-                float ty = ap_quad_xor2(v[c].y) + s1 * v[c].y;
-                const float rx = rot ? ty : tx;          // * (-i) on lane 3
-                const float ry = rot ? -tx : ty;
-                v[c].x = ap_quad_xor1(rx) + s2 * rx;
-                v[c].y = ap_quad_xor1(ry) + s2 * ry;
-            }
-            // ---- transpose #2: natural order Z[k], k = k1 + 16 c + 256 d ------------
-#pragma unroll
-            for (int c = 0; c < 16; ++c) X[apw_zidx(k1p + 16 * c + 256 * qd)] = v[c];
-            AP_WAVE_SYNC();
-            // ---- paired real split: bins k = lane + 64 r and 1024 - k ----------------
-            //   a2 = Z[k] + conj Z[1024-k], d2 = Z[k] - conj Z[1024-k], u = W^k d2
-            //   2X[k] = (a2.x + u.y, a2.y - u.x),  2X[1024-k] = (a2.x - u.y, -a2.y - u.x)
-            // every Z value is read into registers first: the plane of |X|^p overwrites Z
-            ap_float2 zk[8], zm[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int k = lane + 64 * r;
-                zk[r] = X[apw_zidx(k)];
-                zm[r] = X[apw_zidx((APW_NC - k) & (APW_NC - 1))];
-            }
-            const ap_float2 zh = X[apw_zidx(APW_NC / 2)];
-            AP_WAVE_SYNC();
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int k = lane + 64 * r;
-                const float ax = zk[r].x + zm[r].x, ay = zk[r].y - zm[r].y;
-                const float dx = zk[r].x - zm[r].x, dy = zk[r].y + zm[r].y;
-                // (cos, sin) of angle(lane) + angle(64 r): angle addition with constants
-                const float wc = tws0.x * APW_C32(r) - tws0.y * APW_S32(r);
-                const float ws = tws0.y * APW_C32(r) + tws0.x * APW_S32(r);
-                const float ux = wc * dx + ws * dy;
-                const float uy = wc * dy - ws * dx;
-                pp[k] = apw_pow2x<PMODE>(ax + uy, ay - ux, P.power);
-                pp[APW_NC - k] = apw_pow2x<PMODE>(ax - uy, -ay - ux, P.power);
-            }
-            if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(2.0f * zh.x, 2.0f * zh.y, P.power);
             AP_WAVE_SYNC();
             // ---- mel contraction of this frame by its own wave (no workgroup barrier) ----
             // parts are sorted by length, so the 64 lanes of one pass run loops of ~equal length
@@ -282,5 +322,98 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             if (g < Gt) ob[(int64_t)m * P.T + g] = otile[e];
         }
         AP_WAVE_SYNC();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// STFT, n_fft = 2048, complex output (B, 1025, T) with T fastest (stft.py:216).
+// The 8 waves of a workgroup transform 8 CONSECUTIVE frames of one clip (one each, same
+// register/LDS transform as above), then transpose through LDS so that every 64-byte
+// segment out[b, k, t0..t0+7] is written by 8 adjacent lanes: 4 chunks of 257 bins,
+// double-buffered, one workgroup barrier per chunk.
+template <int PADGEN>
+__global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApStftWaveParams P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);
+    ap_float2 *OB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);        // [2][257][9]
+    apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid,
+                    64 * APS_WAVES);
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    __syncthreads();
+
+    const int F = APW_NC + 1;
+    ap_float2 raw[16];
+    auto load_frame = [&](int64_t group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t = (group - b * P.groups_per_clip) * APS_WAVES + wave;
+        const float *yb = P.y + b * P.L;
+        const ApClip clip = ap_clip_make(yb, P.L);
+        const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
+        // frames beyond T read past the clip: zeros (constant) or clamped garbage (never stored)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int64_t p = base + 2 * (lane + 64 * j);
+            if (PADGEN)
+                raw[j] = t < P.T ? ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode),
+                                         ap_load_padded(yb, P.L, p + 1, P.pad_mode))
+                                 : ap_mk(0.0f, 0.0f);
+            else
+                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+        }
+    };
+    if ((int64_t)blockIdx.x < P.n_groups) load_frame(blockIdx.x);
+
+    for (int64_t group = blockIdx.x; group < P.n_groups; group += gridDim.x) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
+        const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
+        ap_float2 *ob = P.out + b * (int64_t)F * P.T + t0;
+
+        ap_float2 v[16];
+        {
+            ap_float2 w[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = ap_mk(raw[j].x * w[j].x, raw[j].y * w[j].y);
+        }
+        AP_SCHED_FENCE();
+        if (group + gridDim.x < P.n_groups) load_frame(group + gridDim.x);   // next group's frame
+        AP_SCHED_FENCE();
+        apw_forward(v, X, TW1, lc);
+        ap_float2 xk[8], xm[8], zh;
+        apw_split(X, lc, xk, xm, zh);
+
+        // ---- transposed store: chunk c holds r = 2c, 2c+1 (bins 64r+lane and 1024-64r-lane) ----
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ap_float2 *buf = OB + (c & 1) * (APS_OB_ROWS * APS_OB_ROW);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * c + rr;
+                buf[(rr * 128 + lane) * APS_OB_ROW + wave] = ap_mk(0.5f * xk[r].x, 0.5f * xk[r].y);
+                buf[(rr * 128 + 64 + lane) * APS_OB_ROW + wave] = ap_mk(0.5f * xm[r].x, 0.5f * xm[r].y);
+            }
+            if (c == 3 && lane == 0) buf[256 * APS_OB_ROW + wave] = ap_mk(zh.x, -zh.y);   // X[512] = conj Z[512]
+            __syncthreads();
+            const int rows = c == 3 ? 257 : 256;
+            for (int e = tid; e < rows * APS_WAVES; e += 64 * APS_WAVES) {
+                const int row = e >> 3, f = e & 7;
+                if (f < Gt) {
+                    const int rr = row >> 7, q = row & 127;
+                    const int r = 2 * c + rr;
+                    const int bin = row == 256 ? APW_NC / 2 : (q < 64 ? 64 * r + q : APW_NC - 64 * r - (q - 64));
+                    ob[(int64_t)bin * P.T + f] = buf[row * APS_OB_ROW + f];
+                }
+            }
+        }
     }
 }

@@ -53,6 +53,18 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
     P.out_c = reinterpret_cast<ap_float2 *>(out);
+    if (n_fft == 2048) {
+        ApStftWaveParams W;
+        int grid = 0;
+        if (ap_prepare_stft_wave(W, P, B, &grid) == AP_OK) {
+            if (grid > 2) grid = 2;   // exercise the persistent group loop
+            if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
+                emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<0>(W); });
+            else
+                emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<1>(W); });
+            return AP_OK;
+        }
+    }
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
     return AP_OK;
 }
