@@ -232,6 +232,24 @@ static inline int ap_prepare_stft_wave(ApStftWaveParams &W, const ApStftParams &
     return AP_OK;
 }
 
+static inline int ap_prepare_irfft_wave(ApIrfftWaveParams &W, const ApIrfftParams &P, int64_t B, int *grid) {
+    W.S = P.S;
+    W.tw = P.tw;
+    W.frames = P.frames;
+    W.T = P.T;
+    W.groups_per_clip = (P.T + APS_WAVES - 1) / APS_WAVES;
+    W.n_groups = W.groups_per_clip * B;
+    int off = APS_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
+    W.off_ob = off; off += ap_align16(2 * APS_OB_ROWS * APS_OB_ROW * (int)sizeof(ap_float2));
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    int64_t g = W.n_groups < 256 ? W.n_groups : 256;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 static inline int ap_prepare_irfft(ApIrfftParams &P, const float *S, int64_t B, int64_t T, int n_fft,
                                    const float *tw, float *frames) {
     if (!S || !tw || !frames) AP_FAIL(AP_ERR_INVALID, "irfft: NULL buffer");

@@ -39,3 +39,11 @@ struct ApStftWaveParams {
     int hop, pad, pad_mode;
     int off_tw2, off_tw1, off_win, off_ob, lds_bytes;
 };
+
+struct ApIrfftWaveParams {
+    const ap_float2 *S;        // (B, 1025, T)
+    const ap_float2 *tw;       // (2048)
+    float *frames;             // (B, T, 2048)
+    int64_t T, groups_per_clip, n_groups;
+    int off_tw2, off_tw1, off_ob, lds_bytes;
+};

@@ -151,6 +151,17 @@ int ap_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const f
     ApIrfftParams P;
     int rc = ap_prepare_irfft(P, S, B, T, n_fft, tw, frames);
     if (rc != AP_OK) return rc;
+    if (n_fft == 2048) {
+        ApIrfftWaveParams W;
+        int grid = 0;
+        if (ap_prepare_irfft_wave(W, P, B, &grid) == AP_OK) {
+            rc = ap_allow_lds(ap_irfft2048_wave_kernel, W.lds_bytes);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(ap_irfft2048_wave_kernel, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
+                               (hipStream_t)stream, W);
+            return ap_check_launch("ap_irfft_frames_f32(wave)");
+        }
+    }
     rc = ap_allow_lds(ap_irfft_generic_kernel, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(ap_irfft_generic_kernel, dim3((unsigned)(P.tiles_per_clip * B)),

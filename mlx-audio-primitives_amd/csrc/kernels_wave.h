@@ -126,6 +126,7 @@ AP_DEV void apw_fill_tables(ap_float2 *tw2, ap_float2 *tw1, ap_float2 *win, cons
 // windowed samples v[j] = z[lane + 64 j]  ->  Z[k] in natural order in the wave's X buffer
 // (slots apw_zidx(k)).  16 x 16 x 4: two in-register radix-16 passes around LDS transpose #1,
 // the radix-4 across the quad with DPP, then LDS transpose #2.
+template <bool TO_LDS = true>
 AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ApwLane &c) {
     const int lane = c.lane;
     {
@@ -161,10 +162,13 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
         v[cc].x = ap_quad_xor1(rx) + c.s2 * rx;
         v[cc].y = ap_quad_xor1(ry) + c.s2 * ry;
     }
-    // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d
+    // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d (skipped when the caller stores
+    // v[cc] = Z[k1p + 16 cc + 256 qd] itself)
+    if (TO_LDS) {
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) X[apw_zidx(c.k1p + 16 * cc + 256 * c.qd)] = v[cc];
-    AP_WAVE_SYNC();
+        for (int cc = 0; cc < 16; ++cc) X[apw_zidx(c.k1p + 16 * cc + 256 * c.qd)] = v[cc];
+        AP_WAVE_SYNC();
+    }
 }
 
 // paired real split from Z in X: xk[r] = 2 X[lane + 64 r], xm[r] = 2 X[1024 - lane - 64 r],
@@ -413,6 +417,101 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
                     const int bin = row == 256 ? APW_NC / 2 : (q < 64 ? 64 * r + q : APW_NC - 64 * r - (q - 64));
                     ob[(int64_t)bin * P.T + f] = buf[row * APS_OB_ROW + f];
                 }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// irfft of every frame, n_fft = 2048: S (B, 1025, T) complex -> frames (B, T, 2048)
+// (transpose + mx.fft.irfft(n=n_fft), stft.py:292-295).  Mirror image of the STFT kernel:
+// the 8 waves of a workgroup take 8 consecutive frames; the (bin, 8 frames) 64-byte
+// segments are staged through LDS in 4 double-buffered chunks so every wave ends up with
+// its own frame's bins k = lane + 64 r and 1024 - k in registers; Hermitian merge, the
+// same 16 x 16 x 4 transform on conjugated data, and 128-byte-coalesced stores straight
+// from the quad outputs (no second LDS transpose).
+__global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(ApIrfftWaveParams P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    ap_float2 *IB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);        // [2][257][9]
+    {
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = P.tw[32 * (tid >> 4) * (tid & 15)];
+        for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
+    }
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    __syncthreads();
+    const int F = APW_NC + 1;
+    const float scale = 1.0f / 2048.0f;
+
+    for (int64_t group = blockIdx.x; group < P.n_groups; group += gridDim.x) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
+        const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
+        const ap_float2 *sb = P.S + b * (int64_t)F * P.T + t0;
+
+        // ---- transposed load: every wave collects its frame's bins in registers -----------
+        ap_float2 xk[8], xm[8], xh = ap_mk(0.0f, 0.0f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ap_float2 *buf = IB + (c & 1) * (APS_OB_ROWS * APS_OB_ROW);
+            const int rows = c == 3 ? 257 : 256;
+            for (int e = tid; e < rows * APS_WAVES; e += 64 * APS_WAVES) {
+                const int row = e >> 3, f = e & 7;
+                const int rr = row >> 7, q = row & 127;
+                const int r = 2 * c + rr;
+                const int bin = row == 256 ? APW_NC / 2 : (q < 64 ? 64 * r + q : APW_NC - 64 * r - (q - 64));
+                buf[row * APS_OB_ROW + f] = f < Gt ? sb[(int64_t)bin * P.T + f] : ap_mk(0.0f, 0.0f);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                xk[2 * c + rr] = buf[(rr * 128 + lane) * APS_OB_ROW + wave];
+                xm[2 * c + rr] = buf[(rr * 128 + 64 + lane) * APS_OB_ROW + wave];
+            }
+            if (c == 3) xh = buf[256 * APS_OB_ROW + wave];
+        }
+        // ---- Hermitian merge: conj(Z[k]) and conj(Z[1024-k]) of the packed inverse ----------
+        //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = W^-k d
+        //   conj Z[k] = (a.x - o.y, -(a.y + o.x)),  conj Z[1024-k] = (a.x + o.y, a.y - o.x)
+        ap_float2 v[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            ap_float2 a_k = xk[r], a_m = xm[r];
+            if (r == 0 && lane == 0) { a_k.y = 0.0f; a_m.y = 0.0f; }      // DC / Nyquist imaginary parts ignored
+            const float ax = a_k.x + a_m.x, ay = a_k.y - a_m.y;
+            const float dx = a_k.x - a_m.x, dy = a_k.y + a_m.y;
+            const float wc = lc.tws0.x * APW_C32(r) - lc.tws0.y * APW_S32(r);
+            const float ws = lc.tws0.y * APW_C32(r) + lc.tws0.x * APW_S32(r);
+            const float ox = wc * dx - ws * dy, oy = wc * dy + ws * dx;     // W^-k = (c, +s)
+            v[r] = ap_mk(ax - oy, -(ay + ox));                               // index lane + 64 r
+            // index 1024 - k belongs to lane 64 - lane (register 15 - r): exchange through LDS
+            const int km = (APW_NC - (lane + 64 * r)) & (APW_NC - 1);
+            if (!(r == 0 && lane == 0)) X[apw_zidx(km)] = ap_mk(ax + oy, ay - ox);
+        }
+        if (lane == 0) {    // bin 512 pairs with itself: conj Z[512] = (2 re, 2 im) of ... see kernels_generic.h
+            const float ax = 2.0f * xh.x, dy = 2.0f * xh.y;                  // a = (2re, 0), d = (0, 2im)
+            // W^-512 = (0, 1): o = (-dy, 0)
+            X[apw_zidx(APW_NC / 2)] = ap_mk(ax, dy);                         // (a.x - o.y, -(a.y + o.x)) = (2re, 2im)
+        }
+        AP_WAVE_SYNC();
+#pragma unroll
+        for (int j = 8; j < 16; ++j) v[j] = X[apw_zidx(lane + 64 * j)];
+        AP_WAVE_SYNC();
+        apw_forward<false>(v, X, TW1, lc);
+        // y[n] = conj(Y[n]) / 2048 -> samples 2n, 2n+1;  n = k1p + 16 c + 256 qd
+        if (wave < Gt) {
+            float *dst = P.frames + ((b * P.T + t0 + wave) * (int64_t)2048);
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int n = lc.k1p + 16 * cc + 256 * lc.qd;
+                *reinterpret_cast<ap_float2 *>(dst + 2 * n) = ap_mk(v[cc].x * scale, -v[cc].y * scale);
             }
         }
     }

@@ -20,6 +20,48 @@ from ._validation import validate_positive, validate_range
 from .stft import istft, stft
 
 
+_RNG_CHUNK = 1 << 20
+
+
+def _random_phase(random_state, shape, device) -> torch.Tensor:
+    """uniform(-pi, pi, shape) from np.random.default_rng(random_state), float64 -> float32,
+    bit-identical to the reference's single host call (griffinlim.py:112-115).
+
+    PCG64 spends exactly one 64-bit output per double, so the stream is cut into chunks
+    whose generators are advanced to their offset and filled by a small thread pool
+    (NumPy releases the GIL while filling); each chunk is copied to the GPU asynchronously
+    from pinned memory while the next ones are still being drawn."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = int(np.prod(shape))
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    if n == 0:
+        return out.reshape(shape)
+    seed_bg = np.random.default_rng(random_state).bit_generator
+    state = seed_bg.state
+    n_chunks = (n + _RNG_CHUNK - 1) // _RNG_CHUNK
+    host = torch.empty(n, dtype=torch.float32)
+    if n > _RNG_CHUNK and torch.device(device).type == "cuda":
+        host = host.pin_memory()
+    host_np = host.numpy()
+
+    def fill(c):
+        lo = c * _RNG_CHUNK
+        hi = min(n, lo + _RNG_CHUNK)
+        bg = np.random.PCG64()
+        bg.state = state
+        bg.advance(lo)
+        host_np[lo:hi] = np.random.Generator(bg).uniform(-np.pi, np.pi, hi - lo)   # f64 -> f32 cast
+        return lo, hi
+
+    workers = max(1, min(16, len(os.sched_getaffinity(0)), n_chunks))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for lo, hi in pool.map(fill, range(n_chunks)):
+            out[lo:hi].copy_(host[lo:hi], non_blocking=True)
+    return out.reshape(shape)
+
+
 def _project(mode, S, angles, R, momentum, tprev, rebuilt):
     B, F, T = S.shape
     TR = R.shape[-1] if R is not None else 0
@@ -51,9 +93,8 @@ def griffinlim(S, n_iter: int = 32, hop_length: int | None = None, win_length: i
     if win_length is None:
         win_length = n_fft
 
-    rng = np.random.default_rng(random_state)
     if init == "random":
-        angles = torch.from_numpy(rng.uniform(-np.pi, np.pi, (B, F, T)).astype(np.float32)).to(dev)
+        angles = _random_phase(random_state, (B, F, T), dev)
     elif init == "zeros":
         angles = torch.zeros((B, F, T), dtype=torch.float32, device=dev)
     else:

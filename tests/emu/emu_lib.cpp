@@ -101,6 +101,15 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
     ApIrfftParams P;
     int rc = ap_prepare_irfft(P, S, B, T, n_fft, tw, frames);
     if (rc != AP_OK) return rc;
+    if (n_fft == 2048) {
+        ApIrfftWaveParams W;
+        int grid = 0;
+        if (ap_prepare_irfft_wave(W, P, B, &grid) == AP_OK) {
+            if (grid > 2) grid = 2;
+            emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel(W); });
+            return AP_OK;
+        }
+    }
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_irfft_generic_kernel(P); });
     return AP_OK;
 }
