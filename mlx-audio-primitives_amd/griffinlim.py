@@ -23,6 +23,20 @@ from .stft import istft, stft
 _RNG_CHUNK = 1 << 20
 
 
+_pinned: dict[str, torch.Tensor] = {}
+
+
+def _staging(n: int, pinned: bool) -> torch.Tensor:
+    """Reusable host staging buffer (page-locking 50+ MB per call costs more than the draw)."""
+    if not pinned:
+        return torch.empty(n, dtype=torch.float32)
+    buf = _pinned.get("buf")
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1 << 22), dtype=torch.float32).pin_memory()
+        _pinned["buf"] = buf
+    return buf[:n]
+
+
 def _random_phase(random_state, shape, device) -> torch.Tensor:
     """uniform(-pi, pi, shape) from np.random.default_rng(random_state), float64 -> float32,
     bit-identical to the reference's single host call (griffinlim.py:112-115).
@@ -41,9 +55,7 @@ def _random_phase(random_state, shape, device) -> torch.Tensor:
     seed_bg = np.random.default_rng(random_state).bit_generator
     state = seed_bg.state
     n_chunks = (n + _RNG_CHUNK - 1) // _RNG_CHUNK
-    host = torch.empty(n, dtype=torch.float32)
-    if n > _RNG_CHUNK and torch.device(device).type == "cuda":
-        host = host.pin_memory()
+    host = _staging(n, torch.device(device).type == "cuda")
     host_np = host.numpy()
 
     def fill(c):
@@ -59,6 +71,8 @@ def _random_phase(random_state, shape, device) -> torch.Tensor:
     with ThreadPoolExecutor(max_workers=workers) as pool:
         for lo, hi in pool.map(fill, range(n_chunks)):
             out[lo:hi].copy_(host[lo:hi], non_blocking=True)
+    if out.is_cuda:
+        torch.cuda.current_stream(out.device).synchronize()   # staging buffer is reused by the next call
     return out.reshape(shape)
 
 
