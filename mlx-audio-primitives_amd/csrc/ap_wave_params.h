@@ -8,6 +8,7 @@
 #define APW_WAVES 8          // waves per workgroup (2 per SIMD; they only share read-only LDS tables)
 #define APW_ROW 18           // padded row (complex) of transpose #1: conflict-free ds_read_b128
 #define APW_X_COMPLEX 1168   // complex slots of one wave's exchange buffer (>= 64*18, >= zidx(1023)+1)
+#define APW_PASSES 4          // contraction passes whose part descriptors live in registers (256 parts)
 #define APW_TW2_COMPLEX 72   // 4 rows x 17 (padded) of W_64^(a*c), rounded to 16 bytes
 
 struct ApMelWaveParams {

@@ -230,6 +230,21 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
     }
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     float *pp = reinterpret_cast<float *>(X);        // |X|^p plane of this wave, aliased on its X buffer
+    // frame-invariant contraction state of this lane: its parts and the slot ranges of its rows
+    ap_int4 mypart[APW_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < APW_PASSES; ++ps) {
+        const int pi = lane + 64 * ps;
+        mypart[ps].x = 0; mypart[ps].y = 0; mypart[ps].z = 0; mypart[ps].w = 0;
+        if (pi < P.n_parts) mypart[ps] = reinterpret_cast<const ap_int4 *>(P.parts)[pi];
+    }
+    int rs0[2], rs1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lane + 64 * i;
+        rs0[i] = row < M ? P.rowstart[row] : 0;
+        rs1[i] = row < M ? P.rowstart[row + 1] : 0;
+    }
     __syncthreads();
 
     // every wave is an independent worker over (clip, APW_G-frame tile) units
@@ -291,11 +306,33 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             }
             AP_WAVE_SYNC();
             // ---- mel contraction of this frame by its own wave (no workgroup barrier) ----
-            // parts are sorted by length, so the 64 lanes of one pass run loops of ~equal length
-            for (int p0 = 0; p0 < P.n_parts; p0 += 64) {
+            // parts are sorted by length, so the 64 lanes of one pass run loops of ~equal length.
+            // The lane's part descriptors are frame-invariant (registers); all LDS reads of a pass
+            // are issued before the first FMA so a pass costs one LDS latency, not one per group.
+#pragma unroll
+            for (int ps = 0; ps < APW_PASSES; ++ps) {
+                const ap_int4 pd = mypart[ps];                     // slot, g0, ng, q0 (ng = 0: idle)
+                const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                const ap_float4 *wq = WQ + pd.w;
+                ap_float4 w[4], q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < pd.z) { w[i] = wq[i]; q[i] = pq[i]; }
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < pd.z) {
+                        acc = fmaf(w[i].x, q[i].x, acc);
+                        acc = fmaf(w[i].y, q[i].y, acc);
+                        acc = fmaf(w[i].z, q[i].z, acc);
+                        acc = fmaf(w[i].w, q[i].w, acc);
+                    }
+                if (pd.z > 0) partial[pd.x] = acc;
+            }
+            for (int p0 = 64 * APW_PASSES; p0 < P.n_parts; p0 += 64) {   // plans with > 256 parts
                 const int pi = p0 + lane;
                 if (pi < P.n_parts) {
-                    const ap_int4 pd = PART[pi];                   // slot, g0, ng, q0
+                    const ap_int4 pd = PART[pi];
                     const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
                     const ap_float4 *wq = WQ + pd.w;
                     float acc = 0.0f;
@@ -312,7 +349,16 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             AP_WAVE_SYNC();
             // a row's partial sums are adjacent; frame t0+g is one column of this wave's
             // (M x APW_G) output tile
-            for (int row = lane; row < M; row += 64) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = lane + 64 * i;
+                if (row < M) {
+                    float sum = 0.0f;
+                    for (int j = rs0[i]; j < rs1[i]; ++j) sum += partial[j];
+                    otile[row * APW_G + g] = sum;
+                }
+            }
+            for (int row = lane + 128; row < M; row += 64) {       // n_mels > 128
                 const int a0 = P.rowstart[row], a1 = P.rowstart[row + 1];
                 float sum = 0.0f;
                 for (int j = a0; j < a1; ++j) sum += partial[j];
