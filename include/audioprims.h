@@ -197,6 +197,19 @@ int ap_resample_poly_f32(const float *x /*dev*/, int64_t B, int64_t L, int up, i
 int ap_resample_linear_f32(const float *x /*dev*/, int64_t B, int64_t L, int64_t n_out,
                            double scale, float *out /*dev*/, void *stream);
 
+/* FFT resampler = scipy.signal.resample(x, num) for real float32 rows (reference
+ * resample.py:97,123): complex FFT of length Nx (four-step, both legs in LDS), SciPy's
+ * Nyquist-aware spectrum truncation / zero-padding, inverse FFT of length num, scale num/Nx.
+ *   ap_cfft_split_host(N, &N1, &N2): N = N1*N2 with both <= 4096, -1 if the length cannot be
+ *     split (then the call below returns AP_ERR_UNSUPPORTED);
+ *   tw_* : twiddle tables (ap_twiddle_table_host) of the four leg lengths on the device;
+ *   ws   : workspace of 2 * B * max(Nx, num) complex64 (= 16 * B * max(Nx,num) bytes). */
+int ap_cfft_split_host(int64_t N, int *N1, int *N2);
+int ap_resample_fft_f32(const float *x /*dev (B,Nx)*/, int64_t B, int64_t Nx, int64_t num,
+                        const float *tw_x1, const float *tw_x2, const float *tw_y1,
+                        const float *tw_y2 /*dev*/, float *ws /*dev*/, float *out /*dev (B,num)*/,
+                        void *stream);
+
 /* magnitude / phase / |S|^p of a complex64 array of n elements —
  * stft.py:347-379 (mx.abs, mx.arctan2). */
 int ap_magnitude_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);

@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "ap_magnitude_f32", "ap_phase_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
-    "ap_from_db_f32", "ap_dct_f32",
+    "ap_from_db_f32", "ap_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
 ]
 
 HAS_HIP_EXT: bool = False
@@ -89,6 +89,8 @@ def _declare(lib) -> None:
         "ap_to_db_f32": [P, L, F, F, F, P, F, P, P, P],
         "ap_from_db_f32": [P, L, F, F, P, P],
         "ap_dct_f32": [P, P, P, L, I, L, I, P, P],
+        "ap_cfft_split_host": [L, P, P],
+        "ap_resample_fft_f32": [P, L, L, L, P, P, P, P, P, P, P],
         "ap_phase_f32": [P, L, P, P],
     }
     for name, argtypes in sig.items():

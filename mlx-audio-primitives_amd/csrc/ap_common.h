@@ -60,6 +60,34 @@ static inline int ap_make_plan(int n_fft, ApFftPlan *p) {
     return 0;
 }
 
+// Plan of a plain complex transform of length nc (used by the large-N four-step FFT).
+static inline int ap_make_cplan(int nc, ApFftPlan *p) {
+    if (nc < 1) return -1;
+    int rc = ap_make_plan(2 * nc, p);      // even real length 2*nc -> complex length nc, same radices
+    if (rc != 0) return rc;
+    p->n = nc;
+    p->even = 0;
+    p->tw_step = 1;                        // the twiddle table is W_nc^j itself
+    return 0;
+}
+
+// N = N1 * N2 with both factors <= AP_CFFT_MAX (LDS-resident); N2 = 1 when N fits.  -1 if impossible.
+#define AP_CFFT_MAX 4096
+static inline int ap_cfft_split(int64_t N, int *N1, int *N2) {
+    if (N < 1) return -1;
+    if (N <= AP_CFFT_MAX) { *N1 = (int)N; *N2 = 1; return 0; }
+    int best = -1;
+    int a0 = 2;
+    while ((int64_t)a0 * a0 < N) ++a0;                                   // ceil(sqrt(N))
+    for (int a = a0; a <= AP_CFFT_MAX; ++a) {                            // most balanced admissible split
+        if (N % a == 0 && N / a <= AP_CFFT_MAX) { best = a; break; }
+    }
+    if (best < 0) return -1;
+    *N1 = best;
+    *N2 = (int)(N / best);
+    return 0;
+}
+
 // LDS geometry of the generic engine: two ping-pong complex buffers per frame,
 // `fstride` float2 per buffer per frame (padded by one to break the power-of-two
 // stride between frames), G frames per workgroup.
@@ -83,6 +111,24 @@ static inline int ap_make_tile(const ApFftPlan *p, int64_t T, ApTile *t) {
     t->lds_bytes = (int)(per_frame * G);
     return 0;
 }
+
+// Strided batched complex FFT (one leg of the four-step transform, kernels_bigfft.h)
+struct ApCfftParams {
+    const void *in;        // ap_float2 (or float when real_in)
+    void *out;             // ap_float2 (or float when real_out)
+    int64_t in_batch, out_batch;     // elements between signals of the batch
+    int64_t in_fs, in_is;            // element strides: frame, index within frame
+    int64_t out_fs, out_is;
+    int64_t n_frames;
+    int64_t tw_N;                    // > 0: multiply output (frame f, bin k) by W_tw_N^(f*k) (forward sign)
+    int64_t tiles_per_signal;
+    const ap_float2 *tw;             // W_n^j table of this leg
+    int conj_io;                     // 1: conjugate input and output (inverse transform)
+    int real_in, real_out;
+    float scale;
+    ApFftPlan plan;
+    ApTile tile;
+};
 
 // Parameters of the fused framing + window + real FFT kernel and its epilogues.
 struct ApStftParams {

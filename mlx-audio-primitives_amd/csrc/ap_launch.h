@@ -232,6 +232,52 @@ static inline int ap_prepare_stft_wave(ApStftWaveParams &W, const ApStftParams &
     return AP_OK;
 }
 
+// One leg of the four-step transform.
+static inline int ap_prepare_cfft_leg(ApCfftParams &C, int n, int64_t n_frames, int64_t B) {
+    if (ap_make_cplan(n, &C.plan) != 0) AP_FAIL(AP_ERR_UNSUPPORTED, "cfft: cannot plan length %d", n);
+    const int fstride = n + 1;
+    const int64_t per_frame = (int64_t)2 * fstride * (int64_t)sizeof(ap_float2);
+    if (per_frame > AP_LDS_MAX) AP_FAIL(AP_ERR_UNSUPPORTED, "cfft: length %d does not fit LDS", n);
+    int G = (int)(AP_LDS_TILE_BUDGET / per_frame);
+    if (G < 1) G = 1;
+    if (G > AP_MAX_G) G = AP_MAX_G;
+    if ((int64_t)G > n_frames) G = (int)n_frames;
+    C.tile.G = G;
+    C.tile.fstride = fstride;
+    C.tile.lds_bytes = (int)(per_frame * G);
+    C.n_frames = n_frames;
+    C.tiles_per_signal = (n_frames + G - 1) / G;
+    if (C.tiles_per_signal * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "cfft: grid too large");
+    return AP_OK;
+}
+
+// Fill the two legs of a length-N complex transform (N = N1*N2) between `in` and `out` through
+// the scratch array `mid` (all B x N complex unless real_in / real_out).
+static inline int ap_prepare_cfft(ApCfftParams &L1, ApCfftParams &L2, const void *in, void *mid,
+                                  void *out, int64_t B, int64_t N, int N1, int N2,
+                                  const float *tw1, const float *tw2, int inverse, int real_in,
+                                  int real_out, float scale) {
+    int rc = ap_prepare_cfft_leg(L1, N1, N2, B);
+    if (rc != AP_OK) return rc;
+    rc = ap_prepare_cfft_leg(L2, N2, N1, B);
+    if (rc != AP_OK) return rc;
+    // leg 1: frames = n2 (N2 of them), index n1 at stride N2; out A[k1*N2 + n2], twiddle W_N^(n2*k1)
+    L1.in = in; L1.out = mid;
+    L1.in_batch = N; L1.out_batch = N;
+    L1.in_fs = 1; L1.in_is = N2; L1.out_fs = 1; L1.out_is = N2;
+    L1.tw_N = N2 > 1 ? N : 0;
+    L1.tw = reinterpret_cast<const ap_float2 *>(tw1);
+    L1.conj_io = inverse; L1.real_in = real_in; L1.real_out = 0; L1.scale = 1.0f;
+    // leg 2: frames = k1 (N1 of them), contiguous rows of length N2; out X[k1 + N1*k2]
+    L2.in = mid; L2.out = out;
+    L2.in_batch = N; L2.out_batch = N;
+    L2.in_fs = N2; L2.in_is = 1; L2.out_fs = 1; L2.out_is = N1;
+    L2.tw_N = 0;
+    L2.tw = reinterpret_cast<const ap_float2 *>(tw2);
+    L2.conj_io = inverse; L2.real_in = 0; L2.real_out = real_out; L2.scale = scale;
+    return AP_OK;
+}
+
 static inline int ap_prepare_irfft_wave(ApIrfftWaveParams &W, const ApIrfftParams &P, int64_t B, int *grid) {
     W.S = P.S;
     W.tw = P.tw;

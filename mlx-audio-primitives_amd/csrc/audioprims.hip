@@ -10,6 +10,7 @@
 #include "kernels_generic.h"
 #include "kernels_wave.h"
 #include "kernels_pointwise.h"
+#include "kernels_bigfft.h"
 
 static thread_local char g_err[512] = "";
 
@@ -279,6 +280,58 @@ int ap_dct_f32(const float *x, const float *C, const float *row_scale, int64_t o
         hipLaunchKernelGGL(ap_dct_kernel<32>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
                            row_scale, outer, n_in, inner, n_out, out);
     return ap_check_launch("ap_dct_f32");
+}
+
+static int ap_launch_cfft_leg(const ApCfftParams &C, int64_t B, void *stream) {
+    int rc = ap_allow_lds(ap_cfft_strided_kernel, C.tile.lds_bytes);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_cfft_strided_kernel, dim3((unsigned)(C.tiles_per_signal * B)), dim3(AP_BLOCK),
+                       C.tile.lds_bytes, (hipStream_t)stream, C);
+    return ap_check_launch("ap_cfft leg");
+}
+
+int ap_cfft_split_host(int64_t N, int *N1, int *N2) {
+    if (!N1 || !N2) return AP_ERR_INVALID;
+    return ap_cfft_split(N, N1, N2) == 0 ? AP_OK : AP_ERR_UNSUPPORTED;
+}
+
+int ap_resample_fft_f32(const float *x, int64_t B, int64_t Nx, int64_t num, const float *tw_x1,
+                        const float *tw_x2, const float *tw_y1, const float *tw_y2, float *ws,
+                        float *out, void *stream) {
+    if (!x || !out || !ws || !tw_x1 || !tw_x2 || !tw_y1 || !tw_y2)
+        AP_FAIL(AP_ERR_INVALID, "resample(fft): NULL buffer");
+    if (B <= 0 || Nx <= 0 || num <= 0) AP_FAIL(AP_ERR_INVALID, "resample(fft): empty signal");
+    int a1, a2, b1, b2;
+    if (ap_cfft_split(Nx, &a1, &a2) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): length %lld has no factorisation N1*N2 with both <= %d",
+                (long long)Nx, AP_CFFT_MAX);
+    if (ap_cfft_split(num, &b1, &b2) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): length %lld has no factorisation N1*N2 with both <= %d",
+                (long long)num, AP_CFFT_MAX);
+    const int64_t Nmax = Nx > num ? Nx : num;
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ws);
+    ap_float2 *bufB = bufA + B * Nmax;
+    ApCfftParams L1, L2;
+    // forward: x (real) -> bufA (leg scratch) -> bufB = X (B, Nx)
+    int rc = ap_prepare_cfft(L1, L2, x, bufA, bufB, B, Nx, a1, a2, tw_x1, tw_x2, 0, 1, 0, 1.0f);
+    if (rc != AP_OK) return rc;
+    L2.out_batch = Nx;
+    rc = ap_launch_cfft_leg(L1, B, stream);
+    if (rc != AP_OK) return rc;
+    rc = ap_launch_cfft_leg(L2, B, stream);
+    if (rc != AP_OK) return rc;
+    // spectrum surgery: bufB (B, Nx) -> bufA (B, num) full Hermitian
+    hipLaunchKernelGGL(ap_resample_spectrum_kernel, dim3(ap_grid_1d(B * num, AP_BLOCK, kApStreamGrid)),
+                       dim3(AP_BLOCK), 0, (hipStream_t)stream, bufB, Nx, bufA, num, B);
+    rc = ap_check_launch("ap_resample_spectrum");
+    if (rc != AP_OK) return rc;
+    // inverse: bufA -> bufB (leg scratch) -> out (real), scale = (1/num) * (num/Nx) = 1/Nx
+    rc = ap_prepare_cfft(L1, L2, bufA, bufB, out, B, num, b1, b2, tw_y1, tw_y2, 1, 0, 1,
+                         (float)(1.0 / (double)Nx));
+    if (rc != AP_OK) return rc;
+    rc = ap_launch_cfft_leg(L1, B, stream);
+    if (rc != AP_OK) return rc;
+    return ap_launch_cfft_leg(L2, B, stream);
 }
 
 static int ap_complex_unary(const float *S, int64_t n, int mode, float *out, void *stream) {

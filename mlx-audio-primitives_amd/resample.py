@@ -3,9 +3,10 @@
 The reference ships every resampler to the host (SciPy / NumPy, resample.py:97,123,
 279-281) and copies the result back.  Here ``resample_poly`` is a polyphase FIR kernel
 that reproduces scipy.signal.resample_poly for float32 input (same taps, same
-accumulation order), and ``res_type='linear'`` is a float64-position interpolation
-kernel.  ``res_type='fft'`` (scipy.signal.resample: one whole-clip FFT of arbitrary
-length) is not on the device yet and raises instead of silently running on the CPU.
+accumulation order), ``res_type='linear'`` is a float64-position interpolation kernel and
+``res_type='fft'`` (scipy.signal.resample: one whole-clip FFT of arbitrary length) is a
+four-step large-N FFT whose two legs both run in LDS (lengths N = N1*N2 with N1, N2 <= 4096;
+anything else raises instead of silently running on the CPU).
 """
 
 from __future__ import annotations
@@ -83,6 +84,35 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
     return _from_rows(out, lead, axis, ndim)
 
 
+def _cfft_split(n: int):
+    import ctypes
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    rc = _x.lib().ap_cfft_split_host(int(n), ctypes.addressof(a), ctypes.addressof(b))
+    if rc != 0:
+        raise ValueError(
+            f"resample(res_type='fft'): length {n} has a prime factor too large for the on-chip "
+            "transform (needs N = N1*N2 with both <= 4096); use resample_poly or res_type='linear'")
+    return a.value, b.value
+
+
+def _resample_fft(rows: torch.Tensor, out: torch.Tensor, post_scale: float) -> None:
+    """scipy.signal.resample on the device (reference resample.py:97,123): four-step complex
+    FFT of the whole clip, SciPy's spectrum surgery, inverse transform."""
+    from .stft import _get_twiddles
+
+    R, L = rows.shape
+    n_out = out.shape[1]
+    dev = rows.device
+    legs = _cfft_split(L) + _cfft_split(n_out)
+    tws = [_get_twiddles(n, dev) for n in legs]
+    ws = torch.empty(4 * R * max(L, n_out), dtype=torch.float32, device=dev)
+    _x.check(_x.lib().ap_resample_fft_f32(_x.ptr(rows), R, L, n_out, _x.ptr(tws[0]), _x.ptr(tws[1]),
+                                          _x.ptr(tws[2]), _x.ptr(tws[3]), _x.ptr(ws), _x.ptr(out),
+                                          _x.stream_ptr(dev)))
+    if post_scale != 1.0:
+        out.mul_(post_scale)        # `scale=True`: y_new *= ratio (resample.py:126-127)
+
+
 def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool = True,
              scale: bool = False, axis: int = -1) -> torch.Tensor:
     """Resample from orig_sr to target_sr (reference resample.py:21-212)."""
@@ -99,12 +129,11 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
     n_out = int(np.round(L * ratio)) if fix else int(np.ceil(L * ratio))
     if n_out == L:
         return _from_rows(rows, lead, axis, ndim)
-    if res_type == "fft":
-        raise NotImplementedError(
-            "resample(res_type='fft') (scipy.signal.resample: a whole-clip FFT of arbitrary "
-            "length) has no HIP kernel yet; use res_type='linear' or resample_poly. "
-            "No CPU fallback is provided on purpose.")
     out = torch.empty((R, n_out), dtype=torch.float32, device=rows.device)
+    if res_type == "fft":
+        if R > 0 and n_out > 0:
+            _resample_fft(rows, out, float(ratio) if scale else 1.0)
+        return _from_rows(out, lead, axis, ndim)
     if R > 0 and n_out > 0:
         _x.check(_x.lib().ap_resample_linear_f32(_x.ptr(rows), R, L, n_out,
                                                  float(ratio) if scale else 1.0, _x.ptr(out),

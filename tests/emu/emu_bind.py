@@ -217,3 +217,21 @@ def dct(x, C, outer, n_in, inner, row_scale=None):
     rs = _p(np.ascontiguousarray(row_scale, np.float32)) if row_scale is not None else None
     _check(lib().emu_dct_f32(_p(x), _p(C), rs, _i64(outer), n_in, _i64(inner), n_out, _p(out)))
     return out
+
+
+def cfft_split(N):
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib().emu_cfft_split(_i64(N), ctypes.byref(a), ctypes.byref(b))
+    return (a.value, b.value) if rc == 0 else None
+
+
+def resample_fft(x, num):
+    x = np.ascontiguousarray(x, np.float32)
+    B, Nx = x.shape
+    (a1, a2), (b1, b2) = cfft_split(Nx), cfft_split(num)
+    tws = [twiddles(n) for n in (a1, a2, b1, b2)]
+    ws = np.zeros(4 * B * max(Nx, num), np.float32)
+    out = np.zeros((B, num), np.float32)
+    _check(lib().emu_resample_fft_f32(_p(x), _i64(B), _i64(Nx), _i64(num), _p(tws[0]), _p(tws[1]),
+                                      _p(tws[2]), _p(tws[3]), _p(ws), _p(out)))
+    return out

@@ -10,6 +10,7 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/kernels_generic.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_pointwise.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_bigfft.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -172,6 +173,30 @@ int emu_dct_f32(const float *x, const float *C, const float *row_scale, int64_t 
         emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32>(x, C, row_scale, outer, n_in, inner, n_out, out); });
     return AP_OK;
 }
+
+int emu_resample_fft_f32(const float *x, int64_t B, int64_t Nx, int64_t num, const float *tw_x1,
+                         const float *tw_x2, const float *tw_y1, const float *tw_y2, float *ws, float *out) {
+    int a1, a2, b1, b2;
+    if (ap_cfft_split(Nx, &a1, &a2) != 0 || ap_cfft_split(num, &b1, &b2) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): unsupported length");
+    const int64_t Nmax = Nx > num ? Nx : num;
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ws);
+    ap_float2 *bufB = bufA + B * Nmax;
+    ApCfftParams L1, L2;
+    int rc = ap_prepare_cfft(L1, L2, x, bufA, bufB, B, Nx, a1, a2, tw_x1, tw_x2, 0, 1, 0, 1.0f);
+    if (rc != AP_OK) return rc;
+    emu_launch((unsigned)(L1.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L1); });
+    emu_launch((unsigned)(L2.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L2); });
+    emu_launch(ap_grid_1d(B * num, AP_BLOCK, kApStreamGrid), AP_BLOCK,
+               [&] { ap_resample_spectrum_kernel(bufB, Nx, bufA, num, B); });
+    rc = ap_prepare_cfft(L1, L2, bufA, bufB, out, B, num, b1, b2, tw_y1, tw_y2, 1, 0, 1, (float)(1.0 / (double)Nx));
+    if (rc != AP_OK) return rc;
+    emu_launch((unsigned)(L1.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L1); });
+    emu_launch((unsigned)(L2.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L2); });
+    return AP_OK;
+}
+
+int emu_cfft_split(int64_t N, int *N1, int *N2) { return ap_cfft_split(N, N1, N2); }
 
 int emu_complex_unary_f32(const float *S, int64_t n, int mode, float *out) {
     emu_launch(ap_grid_1d(n, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] {

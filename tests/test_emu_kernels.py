@@ -179,3 +179,14 @@ def test_emu_db_dct_and_gl_projection():
     Rn = (Sm * np.exp(1j * np.angle(Rp).astype(np.float64))).astype(np.complex64)
     np.testing.assert_allclose(tp2, Rn, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(reb2, Rn + np.float32(0.99) * (Rn - want), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("Nx,num,B", [(1000, 500, 2), (1000, 1500, 1), (1001, 367, 1), (22050, 11025, 1),
+                                      (4800, 4410, 2), (6, 4, 1)])
+def test_emu_resample_fft_matches_scipy(Nx, num, B):
+    """Four-step large-N FFT + SciPy's spectrum surgery == scipy.signal.resample."""
+    import scipy.signal
+    x = np.random.default_rng(Nx).standard_normal((B, Nx)).astype(np.float32)
+    np.testing.assert_allclose(eb.resample_fft(x, num), scipy.signal.resample(x, num, axis=-1),
+                               rtol=1e-4, atol=1e-5)
+    assert eb.cfft_split(9001) is None and eb.cfft_split(22050) == (150, 147)

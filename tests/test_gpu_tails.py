@@ -74,8 +74,32 @@ def test_resample_linear_and_errors(random_signal):
     assert ap.resample(y, 22050, 22050) is y
     with pytest.raises(ValueError, match="Unknown res_type"):
         ap.resample(y, 22050, 16000, res_type="sinc")
-    with pytest.raises(NotImplementedError):
-        ap.resample(y, 22050, 11025, res_type="fft")
+
+
+def test_resample_fft_matches_scipy_fixtures_and_oracle(random_signal):
+    # fixtures: scipy.signal.resample itself = the reference's implementation (resample.py:97,123)
+    z = load_golden("resample_scipy.npz")
+    for tag, num in (("f_half", 2400), ("f_up", 1500), ("f_odd", 367), ("f_b", 1102)):
+        x = z[f"{tag}_y"]
+        x2 = x if x.ndim == 2 else x[None]
+        L = x2.shape[-1]
+        got = host(ap.resample(dev(x2), L, num, res_type="fft"))     # ratio num/L -> target length num
+        want = z[f"{tag}_out"] if x.ndim == 2 else z[f"{tag}_out"][None]
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4, err_msg=tag)
+    # tests/test_resample.py:39-99: 2x down, 2x up, odd ratios, scale
+    y = dev(random_signal)
+    for orig, target in ((22050, 11025), (11025, 22050), (22050, 16000), (44100, 48000)):
+        got = host(ap.resample(y, orig, target))
+        want = ao.resample(random_signal, orig, target)
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(ap.resample(y, 22050, 16000, scale=True)),
+                               ao.resample(random_signal, 22050, 16000, scale=True), rtol=1e-4, atol=1e-4)
+    assert ap.resample(y, 22050, 16000, fix=False).shape == ao.resample(random_signal, 22050, 16000, fix=False).shape
+    # a length with a prime factor > 4096 cannot be transformed on chip: loud error, no CPU fallback
+    with pytest.raises(ValueError, match="prime factor"):
+        ap.resample(dev(np.zeros(9001, np.float32)), 9001, 4500)
 
 
 # ------------------------------------------------------------------ dB / DCT / MFCC
