@@ -171,6 +171,7 @@ static inline bool ap_mel_wave_eligible(int n_fft, const int32_t *plan, const in
 
 static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P, int64_t B,
                                       const int32_t *plan, const int32_t *desc, int *grid) {
+    const int n_waves = APW_WAVES, x_complex = APW_X_COMPLEX;
     const int M = P.n_mels;
     W.y = P.y;
     W.window = P.window;
@@ -185,23 +186,24 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.T = P.T;
     W.tiles_per_clip = (P.T + APW_G - 1) / APW_G;
     W.n_tiles = W.tiles_per_clip * B;
+    W.n_clips = B;
     W.hop = P.hop;
     W.pad = P.pad;
     W.pad_mode = P.pad_mode;
     W.n_mels = M;
     W.power = P.power;
-    int off = APW_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
+    int off = n_waves * x_complex * (int)sizeof(ap_float2);
     W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
     W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
     W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
     W.off_wq = off; off += ap_align16(W.n_quads * 16);
     W.off_parts = off; off += ap_align16(W.n_parts * 16);
-    W.off_partial = off; off += ap_align16(APW_WAVES * W.n_parts * 4);
-    W.off_otile = off; off += ap_align16(APW_WAVES * M * APW_G * 4);
+    W.off_partial = off; off += ap_align16(n_waves * W.n_parts * 4);
+    W.off_otile = off; off += ap_align16(n_waves * M * APW_G * 4);
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;     // does not fit: caller falls back to the generic engine
     // persistent: one 8-wave workgroup per CU; every wave strides over the tiles on its own
-    int64_t g = (W.n_tiles + APW_WAVES - 1) / APW_WAVES;
+    int64_t g = (W.n_tiles + n_waves - 1) / n_waves;
     if (g > 256) g = 256;
     *grid = (int)g;
     return AP_OK;

@@ -19,7 +19,7 @@ struct ApMelWaveParams {
     const float *quads;        // (n_quads, 4) filter weights of the 4 bins of a group
     const int32_t *rowstart;   // (M+1) slot range of every row
     float *out;                // (B, M, T)
-    int64_t L, T, tiles_per_clip, n_tiles;
+    int64_t L, T, tiles_per_clip, n_tiles, n_clips;
     int hop, pad, pad_mode, n_mels, n_parts, n_quads;
     float power;
     // LDS carve-up (bytes from the start of dynamic LDS)

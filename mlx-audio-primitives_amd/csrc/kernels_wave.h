@@ -247,15 +247,18 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
     }
     __syncthreads();
 
-    // every wave is an independent worker over (clip, APW_G-frame tile) units
-    // adjacent waves take adjacent tiles: their overlapping samples and the neighbouring
-    // 32-byte output segments then meet in the same L1 / L2
+    // every wave is an independent worker: worker w owns the global frames
+    // [w*Ftot/W, (w+1)*Ftot/W) of the flattened (clip, frame) stream (equal shares whatever B and
+    // T are) and walks them in runs of <= APW_G consecutive frames of one clip.  Adjacent waves own
+    // adjacent stretches: their overlapping samples and neighbouring output segments meet in L2.
     const int64_t worker = (int64_t)blockIdx.x * APW_WAVES + wave;
     const int64_t n_workers = (int64_t)gridDim.x * APW_WAVES;
+    const int64_t n_frames = P.n_clips * P.T;
+    const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
     ap_float2 raw[16];
-    auto load_frame = [&](int64_t tile, int g) {
-        const int64_t b = tile / P.tiles_per_clip;
-        const int64_t t = (tile - b * P.tiles_per_clip) * APW_G + g;
+    auto load_frame = [&](int64_t f) {
+        const int64_t b = f / P.T;
+        const int64_t t = f - b * P.T;
         const float *yb = P.y + b * P.L;
         const ApClip clip = ap_clip_make(yb, P.L);
         const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
@@ -269,12 +272,15 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
                 raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
         }
     };
-    if (worker < P.n_tiles) load_frame(worker, 0);
+    if (f_lo < f_hi) load_frame(f_lo);
 
-    for (int64_t tile = worker; tile < P.n_tiles; tile += n_workers) {
-        const int64_t b = tile / P.tiles_per_clip;
-        const int64_t t0 = (tile - b * P.tiles_per_clip) * APW_G;
-        const int Gt = (int)((P.T - t0) < APW_G ? (P.T - t0) : APW_G);
+    for (int64_t f = f_lo; f < f_hi;) {
+        const int64_t b = f / P.T;
+        const int64_t t0 = f - b * P.T;
+        int64_t run = P.T - t0;
+        if (run > APW_G) run = APW_G;
+        if (run > f_hi - f) run = f_hi - f;
+        const int Gt = (int)run;
         float *ob = P.out + b * (int64_t)M * P.T + t0;
 
         for (int g = 0; g < Gt; ++g) {
@@ -289,8 +295,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             // issue the next frame's loads only AFTER the old samples are consumed: otherwise the
             // compiler hoists them and then has to wait vmcnt(0) for them inside this frame
             AP_SCHED_FENCE();
-            if (g + 1 < Gt) load_frame(tile, g + 1);                 // in flight during this frame
-            else if (tile + n_workers < P.n_tiles) load_frame(tile + n_workers, 0);
+            if (f + g + 1 < f_hi) load_frame(f + g + 1);            // next frame, in flight during this one
             AP_SCHED_FENCE();
             apw_forward(v, X, TW1, lc);
             {
@@ -372,6 +377,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             if (g < Gt) ob[(int64_t)m * P.T + g] = otile[e];
         }
         AP_WAVE_SYNC();
+        f += Gt;
     }
 }
 
