@@ -138,6 +138,7 @@ struct ApStftParams {
     int64_t L;
     int64_t T;
     int64_t tiles_per_clip;
+    int64_t n_clips;
     int hop;
     int pad;               // left padding in samples (n_fft/2 if center else 0)
     int pad_mode;
@@ -153,6 +154,11 @@ struct ApStftParams {
     const int32_t *band_len;
     int n_mels;
     float power;
+    // contraction plan (ap_mel_plan_host): parts / weight quads / slot range of every row
+    const int32_t *parts;
+    const float *quads;
+    const int32_t *rowstart;
+    int n_parts, n_quads;
 };
 
 struct ApIrfftParams {

@@ -127,6 +127,7 @@ static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, in
     P.L = L;
     P.T = T;
     P.tiles_per_clip = (T + P.tile.G - 1) / P.tile.G;
+    P.n_clips = B;
     P.hop = hop;
     P.pad = pad;
     P.pad_mode = pad_mode;
@@ -138,6 +139,11 @@ static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, in
     P.band_len = nullptr;
     P.n_mels = 0;
     P.power = 2.0f;
+    P.parts = nullptr;
+    P.quads = nullptr;
+    P.rowstart = nullptr;
+    P.n_parts = 0;
+    P.n_quads = 0;
     if (P.tiles_per_clip * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "stft: grid too large");
     return AP_OK;
 }
@@ -158,6 +164,12 @@ static inline int ap_prepare_mel(ApStftParams &P, const float *fb, const int32_t
     P.band_len = banded ? plan + desc[5] : nullptr;
     P.n_mels = n_mels;
     P.power = power;
+    const bool has_parts = plan && (desc[0] & AP_PLAN_PARTS);
+    P.parts = has_parts ? plan + desc[6] : nullptr;
+    P.n_parts = has_parts ? desc[7] : 0;
+    P.quads = has_parts ? reinterpret_cast<const float *>(plan + desc[8]) : nullptr;
+    P.n_quads = has_parts ? desc[9] : 0;
+    P.rowstart = has_parts ? plan + desc[10] : nullptr;
     return AP_OK;
 }
 
@@ -207,6 +219,22 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     if (g > 256) g = 256;
     *grid = (int)g;
     return AP_OK;
+}
+
+// compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
+static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels, int *G, int *lds_bytes) {
+    int g;
+    if (n_fft == 400) g = 16;
+    else if (n_fft == 512) g = 16;
+    else if (n_fft == 1024) g = 8;
+    else return false;
+    const int nc = n_fft / 2;
+    *G = g;
+    int bytes = (2 * g * (nc + 1) + n_fft + nc) * (int)sizeof(ap_float2);
+    // mel plan tables + partial sums [n_parts][G] + rowstart
+    bytes += n_quads * 16 + n_parts * 16 + n_parts * g * 4 + (n_parts > 0 ? (n_mels + 1) * 4 : 0) + 64;
+    *lds_bytes = bytes;
+    return bytes <= AP_LDS_MAX;
 }
 
 // n_fft = 2048 STFT wave kernel geometry

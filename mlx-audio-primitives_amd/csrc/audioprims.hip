@@ -11,6 +11,7 @@
 #include "kernels_wave.h"
 #include "kernels_pointwise.h"
 #include "kernels_bigfft.h"
+#include "kernels_ct.h"
 
 static thread_local char g_err[512] = "";
 
@@ -42,6 +43,32 @@ static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) 
     hipLaunchKernelGGL((ap_mel2048_wave_kernel<PMODE, PADGEN>), dim3(grid), dim3(64 * APW_WAVES), W.lds_bytes,
                        (hipStream_t)stream, W);
     return ap_check_launch("ap_melspec_f32(wave)");
+}
+
+// compile-time specialised engine for n_fft = 400 / 512 / 1024 (kernels_ct.h)
+template <int EPI, int PADGEN>
+static int ap_launch_ct(ApStftParams &P, int n_fft, int64_t B, void *stream, bool *handled) {
+    int G = 0, lds = 0;
+    *handled = false;
+    if (!ap_ct_config(n_fft, EPI == 1 ? P.n_parts : 0, EPI == 1 ? P.n_quads : 0, P.n_mels, &G, &lds)) return AP_OK;
+    P.tiles_per_clip = (P.T + G - 1) / G;
+    int64_t tiles = P.tiles_per_clip * B;
+    const int per_cu = AP_LDS_MAX / lds < 8 ? AP_LDS_MAX / lds : 8;
+    int64_t grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    int rc = AP_OK;
+#define AP_CT_LAUNCH(NC, R0, R1, R2, GG)                                                             \
+    do {                                                                                             \
+        rc = ap_allow_lds(ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN>, lds);                  \
+        if (rc != AP_OK) return rc;                                                                  \
+        hipLaunchKernelGGL((ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN>), dim3((unsigned)grid), \
+                           dim3(AP_BLOCK), lds, (hipStream_t)stream, P);                             \
+    } while (0)
+    if (n_fft == 400) AP_CT_LAUNCH(200, 8, 5, 5, 16);
+    else if (n_fft == 512) AP_CT_LAUNCH(256, 16, 16, 1, 16);
+    else AP_CT_LAUNCH(512, 16, 8, 4, 8);
+#undef AP_CT_LAUNCH
+    *handled = true;
+    return ap_check_launch("ap_stft_ct");
 }
 
 template <int PADGEN>
@@ -114,6 +141,12 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
             return ap_check_launch("ap_stft_f32(wave)");
         }
     }
+    {
+        bool handled = false;
+        rc = (P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? ap_launch_ct<0, 0>(P, n_fft, B, stream, &handled)
+                                                           : ap_launch_ct<0, 1>(P, n_fft, B, stream, &handled);
+        if (rc != AP_OK || handled) return rc;
+    }
     rc = ap_allow_lds(ap_stft_generic_kernel<0>, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(ap_stft_generic_kernel<0>, dim3((unsigned)(P.tiles_per_clip * B)),
@@ -139,6 +172,12 @@ int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, con
                 return ap_launch_mel_wave_p<0>(W, grid, power, stream);
             return ap_launch_mel_wave_p<1>(W, grid, power, stream);
         }
+    }
+    if (!(desc && (desc[0] & AP_PLAN_FORCE_GENERIC))) {
+        bool handled = false;
+        rc = (P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? ap_launch_ct<1, 0>(P, n_fft, B, stream, &handled)
+                                                           : ap_launch_ct<1, 1>(P, n_fft, B, stream, &handled);
+        if (rc != AP_OK || handled) return rc;
     }
     rc = ap_allow_lds(ap_stft_generic_kernel<1>, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;

@@ -1,0 +1,196 @@
+// Compile-time specialisations of the LDS Stockham engine for the common small transforms
+// (n_fft = 400 Whisper, 512, 1024): same data flow as ap_stft_generic_kernel, but the radix
+// plan, the complex length NC and the tile height G are template constants (all index
+// div/mod fold to shifts and multiplies), the window and the twiddle table are staged in LDS
+// once per workgroup, and constant padding comes from the bounds-checked clip buffer instead
+// of per-sample branches.  Workgroups are persistent over tiles.
+#pragma once
+#include "kernels_generic.h"
+#include "kernels_wave.h"     // ApClip / ap_clip_load / ap_float4
+
+template <int R, int NC, int NS, int G>
+AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_float2 *twl, int tid) {
+    constexpr int PER = NC / R;
+    constexpr int FS = NC + 1;
+    constexpr int TMUL = (NC / (NS * R)) * 2;          // W_{NS*R}^1 in the W_n table (n = 2 NC)
+    for (int item = tid; item < G * PER; item += AP_BLOCK) {
+        const int g = item / PER;
+        const int j = item - g * PER;
+        const ap_float2 *src = in + g * FS;
+        ap_float2 *dst = out + g * FS;
+        const int k = j % NS;
+        ap_float2 v[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) v[i] = src[j + i * PER];
+        if (NS > 1) {
+            const int tk = TMUL * k;
+#pragma unroll
+            for (int i = 1; i < R; ++i) v[i] = ap_mul_fw(v[i], twl[tk * i]);
+        }
+        ApButterfly<R>::run(v);
+        const int j0 = (j / NS) * NS * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) dst[j0 + q * NS] = v[q];
+    }
+}
+
+// EPI 0: complex (B,F,T); EPI 1: mel (B,M,T).  R2 = 1: two passes only.
+template <int EPI, int NC, int R0, int R1, int R2, int G, int PADGEN>
+__global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
+    constexpr int FS = NC + 1;
+    constexpr int N = 2 * NC;
+    constexpr int F = NC + 1;
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
+    ap_float2 *bufB = bufA + G * FS;
+    ap_float2 *twl = bufB + G * FS;                    // [N] (cos, sin)(2 pi j / N)
+    ap_float2 *winl = twl + N;                         // [NC] window pairs
+    // mel plan tables (EPI 1 with a parts plan): weight quads, part descriptors, partial sums, row slots
+    ap_float4 *wql = reinterpret_cast<ap_float4 *>(winl + NC);
+    ap_int4 *partl = reinterpret_cast<ap_int4 *>(wql + P.n_quads);
+    float *partial = reinterpret_cast<float *>(partl + P.n_parts);            // [n_parts][G]
+    int *rsl = reinterpret_cast<int *>(partial + P.n_parts * G);              // [M+1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += AP_BLOCK) twl[i] = P.tw[i];
+    for (int i = tid; i < NC; i += AP_BLOCK) winl[i] = reinterpret_cast<const ap_float2 *>(P.window)[i];
+    if (EPI == 1 && P.n_parts > 0) {
+        for (int i = tid; i < P.n_quads; i += AP_BLOCK) wql[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
+        for (int i = tid; i < P.n_parts; i += AP_BLOCK) partl[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
+        for (int i = tid; i <= P.n_mels; i += AP_BLOCK) rsl[i] = P.rowstart[i];
+    }
+    __syncthreads();
+
+    const int64_t n_tiles = P.tiles_per_clip * P.n_clips;
+    // the samples of a tile are fetched one tile ahead into registers (NI pairs per thread), so
+    // the HBM latency of tile i+1 hides behind the transform of tile i
+    constexpr int NI = (G * NC + AP_BLOCK - 1) / AP_BLOCK;
+    ap_float2 raw[NI];
+    auto load_tile = [&](int64_t tile) {
+        const int64_t b = tile / P.tiles_per_clip;
+        const int64_t t0 = (tile - b * P.tiles_per_clip) * G;
+        const float *yb = P.y + b * P.L;
+        const ApClip clip = ap_clip_make(yb, P.L);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + i * AP_BLOCK;
+            const int g = item / NC;
+            const int c = item - g * NC;
+            raw[i] = ap_mk(0.0f, 0.0f);
+            if (item < G * NC && t0 + g < P.T) {
+                const int64_t p = (t0 + g) * (int64_t)P.hop - P.pad + 2 * c;
+                if (PADGEN)
+                    raw[i] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+                else
+                    raw[i] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+            }
+        }
+    };
+    if ((int64_t)blockIdx.x < n_tiles) load_tile(blockIdx.x);
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b = tile / P.tiles_per_clip;
+        const int64_t t0 = (tile - b * P.tiles_per_clip) * G;
+        const int Gt = (int)((P.T - t0) < G ? (P.T - t0) : G);
+
+        // ---- window + pack as complex into LDS; then put the next tile's loads in flight ----
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int item = tid + i * AP_BLOCK;
+            if (item < G * NC) {
+                const int g = item / NC;
+                const int c = item - g * NC;
+                const ap_float2 w = winl[c];
+                bufA[g * FS + c] = ap_mk(w.x * raw[i].x, w.y * raw[i].y);
+            }
+        }
+#ifndef AP_HOST_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);
+#ifndef AP_HOST_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        __syncthreads();
+        ap_stockham_pass_ct<R0, NC, 1, G>(bufA, bufB, twl, tid);
+        __syncthreads();
+        ap_stockham_pass_ct<R1, NC, R0, G>(bufB, bufA, twl, tid);
+        __syncthreads();
+        ap_float2 *Z = bufA;
+        ap_float2 *other = bufB;
+        if (R2 > 1) {
+            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G>(bufA, bufB, twl, tid);
+            __syncthreads();
+            Z = bufB;
+            other = bufA;
+        }
+
+        if (EPI == 0) {
+            for (int item = tid; item < F * G; item += AP_BLOCK) {
+                const int k = item / G;
+                const int g = item - k * G;
+                if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split(Z + g * FS, NC, k, twl);
+            }
+            __syncthreads();
+        } else {
+            float *Pw = reinterpret_cast<float *>(other);
+            constexpr int PS = (2 * FS) & ~3;                  // 16-byte aligned planes, >= F + 3
+            for (int item = tid; item < F * G; item += AP_BLOCK) {
+                const int k = item / G;
+                const int g = item - k * G;
+                const ap_float2 X = ap_rfft_split(Z + g * FS, NC, k, twl);
+                Pw[g * PS + k] = ap_pow_mag(X.x, X.y, P.power);
+            }
+            if (P.n_parts > 0) {
+                // zero the alignment tail of every plane: the last weight quad may reach past bin F-1
+                for (int item = tid; item < 3 * G; item += AP_BLOCK) {
+                    const int g = item / 3, k = F + (item - g * 3);
+                    if (k < PS) Pw[g * PS + k] = 0.0f;
+                }
+            }
+            __syncthreads();
+            if (P.n_parts > 0) {
+                // plan-based banded contraction, everything from LDS (16-byte reads)
+                for (int item = tid; item < P.n_parts * G; item += AP_BLOCK) {
+                    const int p = item / G;
+                    const int g = item - p * G;
+                    const ap_int4 pd = partl[p];                       // slot, g0, ng, q0
+                    const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(Pw + g * PS) + pd.y;
+                    const ap_float4 *wq = wql + pd.w;
+                    float acc = 0.0f;
+                    for (int i = 0; i < pd.z; ++i) {
+                        const ap_float4 w = wq[i], q = pq[i];
+                        acc = fmaf(w.x, q.x, acc);
+                        acc = fmaf(w.y, q.y, acc);
+                        acc = fmaf(w.z, q.z, acc);
+                        acc = fmaf(w.w, q.w, acc);
+                    }
+                    partial[pd.x * G + g] = acc;
+                }
+                __syncthreads();
+                for (int item = tid; item < P.n_mels * G; item += AP_BLOCK) {
+                    const int m = item / G;
+                    const int g = item - m * G;
+                    if (g < Gt) {
+                        float sum = 0.0f;
+                        for (int j = rsl[m]; j < rsl[m + 1]; ++j) sum += partial[j * G + g];
+                        P.out_mel[(b * P.n_mels + m) * P.T + t0 + g] = sum;
+                    }
+                }
+            } else {
+                for (int item = tid; item < P.n_mels * G; item += AP_BLOCK) {
+                    const int m = item / G;
+                    const int g = item - m * G;
+                    if (g < Gt) {
+                        const int lo = P.band_lo ? P.band_lo[m] : 0;
+                        const int len = P.band_len ? P.band_len[m] : F;
+                        const float *w = P.fb + (int64_t)m * F + lo;
+                        const float *pp = Pw + g * PS + lo;
+                        float acc = 0.0f;
+                        for (int i = 0; i < len; ++i) acc = fmaf(w[i], pp[i], acc);
+                        P.out_mel[(b * P.n_mels + m) * P.T + t0 + g] = acc;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}

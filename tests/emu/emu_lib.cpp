@@ -11,10 +11,24 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_pointwise.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_bigfft.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_ct.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
 void ap_set_error(const char *msg) { std::snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+template <int EPI, int PADGEN>
+static bool emu_launch_ct(ApStftParams &P, int n_fft, int64_t B) {
+    int G = 0, lds = 0;
+    if (!ap_ct_config(n_fft, EPI == 1 ? P.n_parts : 0, EPI == 1 ? P.n_quads : 0, P.n_mels, &G, &lds)) return false;
+    P.tiles_per_clip = (P.T + G - 1) / G;
+    int64_t tiles = P.tiles_per_clip * B;
+    unsigned grid = (unsigned)(tiles < 3 ? tiles : 3);        // exercise the persistent loop
+    if (n_fft == 400) emu_launch(grid, AP_BLOCK, [&] { ap_stft_ct_kernel<EPI, 200, 8, 5, 5, 16, PADGEN>(P); });
+    else if (n_fft == 512) emu_launch(grid, AP_BLOCK, [&] { ap_stft_ct_kernel<EPI, 256, 16, 16, 1, 16, PADGEN>(P); });
+    else emu_launch(grid, AP_BLOCK, [&] { ap_stft_ct_kernel<EPI, 512, 16, 8, 4, 8, PADGEN>(P); });
+    return true;
+}
 
 extern "C" {
 
@@ -66,6 +80,8 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
             return AP_OK;
         }
     }
+    if ((P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? emu_launch_ct<0, 0>(P, n_fft, B) : emu_launch_ct<0, 1>(P, n_fft, B))
+        return AP_OK;
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
     return AP_OK;
 }
@@ -92,6 +108,10 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
             else emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 1>(W); });
             return AP_OK;
         }
+    }
+    if (!(desc && (desc[0] & AP_PLAN_FORCE_GENERIC))) {
+        if ((P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? emu_launch_ct<1, 0>(P, n_fft, B) : emu_launch_ct<1, 1>(P, n_fft, B))
+            return AP_OK;
     }
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<1>(P); });
     return AP_OK;
