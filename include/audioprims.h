@@ -229,6 +229,24 @@ int ap_gl_project_f32(int mode, const float *S /*dev (BF,T)*/, const float *angl
                       float momentum, float *tprev /*dev (BF,T,2)*/, float *rebuilt /*dev*/,
                       void *stream);
 
+/* out[i] = float32(low + (high-low) * next_double_i) of NumPy's PCG64 stream whose CURRENT state
+ * is (state, inc) as reported by numpy.random.default_rng(seed).bit_generator.state, split in
+ * 64-bit halves — i.e. exactly default_rng(seed).uniform(low, high, n).astype(float32)
+ * (reference griffinlim.py:112-115), generated on the device. */
+int ap_pcg64_uniform_f32(uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo,
+                         double low, double high, int64_t n, float *out /*dev*/, void *stream);
+
+/* The whole Griffin-Lim loop (griffinlim.py:123-191) enqueued by ONE call: rebuilt = S*exp(i*angles);
+ * n_iter x { istft -> stft -> project+momentum }; final istft.  All buffers are the caller's:
+ *   rebuilt, tprev : (B,F,T) complex64 scratch      R : (B,F,TR) complex64 scratch, TR = frames of stft(y)
+ *   frames_ws : (B,T,n_fft) float32                 y : (B, y_len) float32 = the result
+ * out_offset / y_len are istft's trim (see ap_istft_f32); TR must equal 1 + (y_len + 2*pad - n_fft)/hop. */
+int ap_griffinlim_f32(const float *S /*dev (B,F,T)*/, const float *angles /*dev (B,F,T)*/, int64_t B,
+                      int64_t T, int n_fft, int hop, const float *window /*dev*/,
+                      const float *tw /*dev*/, int center, int pad_mode, int64_t out_offset,
+                      int64_t y_len, int64_t TR, int n_iter, float momentum, float *rebuilt,
+                      float *tprev, float *R, float *frames_ws, float *y /*dev*/, void *stream);
+
 /* max over n floats into *key_dev (uint32 order-preserving key; caller provides the
  * 4-byte word, the call resets it first).  Used for ref=max and by ap_to_db_f32. */
 int ap_reduce_max_f32(const float *x /*dev*/, int64_t n, uint32_t *key_dev, void *stream);

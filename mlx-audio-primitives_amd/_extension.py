@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
     "ap_from_db_f32", "ap_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
+    "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
 ]
 
 HAS_HIP_EXT: bool = False
@@ -90,6 +91,9 @@ def _declare(lib) -> None:
         "ap_from_db_f32": [P, L, F, F, P, P],
         "ap_dct_f32": [P, P, P, L, I, L, I, P, P],
         "ap_cfft_split_host": [L, P, P],
+        "ap_pcg64_uniform_f32": [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
+                                 ctypes.c_double, ctypes.c_double, L, P, P],
+        "ap_griffinlim_f32": [P, P, L, L, I, I, P, P, I, I, L, L, L, I, F, P, P, P, P, P, P],
         "ap_resample_fft_f32": [P, L, L, L, P, P, P, P, P, P, P],
         "ap_phase_f32": [P, L, P, P],
     }

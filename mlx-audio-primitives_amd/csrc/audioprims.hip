@@ -265,6 +265,38 @@ int ap_gl_project_f32(int mode, const float *S, const float *angles, const float
     return ap_check_launch("ap_gl_project_f32");
 }
 
+int ap_pcg64_uniform_f32(uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo,
+                         double low, double high, int64_t n, float *out, void *stream) {
+    if (n < 0 || (n > 0 && !out)) AP_FAIL(AP_ERR_INVALID, "pcg64_uniform: bad buffer");
+    if (n == 0) return AP_OK;
+    hipLaunchKernelGGL(ap_pcg64_uniform_kernel, dim3(ap_grid_1d(n, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, (unsigned long long)state_hi, (unsigned long long)state_lo,
+                       (unsigned long long)inc_hi, (unsigned long long)inc_lo, low, high - low, n, out);
+    return ap_check_launch("ap_pcg64_uniform_f32");
+}
+
+int ap_griffinlim_f32(const float *S, const float *angles, int64_t B, int64_t T, int n_fft, int hop,
+                      const float *window, const float *tw, int center, int pad_mode,
+                      int64_t out_offset, int64_t y_len, int64_t TR, int n_iter, float momentum,
+                      float *rebuilt, float *tprev, float *R, float *frames_ws, float *y, void *stream) {
+    if (!S || !angles || !rebuilt || !tprev || !R || !frames_ws || !y)
+        AP_FAIL(AP_ERR_INVALID, "griffinlim: NULL buffer");
+    if (n_iter <= 0) AP_FAIL(AP_ERR_INVALID, "n_iter must be positive, got %d", n_iter);
+    if (momentum < 0.0f || momentum >= 1.0f) AP_FAIL(AP_ERR_INVALID, "momentum must be in [0, 1)");
+    const int64_t F = n_fft / 2 + 1;
+    int rc = ap_gl_project_f32(0, S, angles, nullptr, 0, B * F, T, 0.0f, tprev, rebuilt, stream);
+    if (rc != AP_OK) return rc;
+    for (int it = 0; it < n_iter; ++it) {
+        rc = ap_istft_f32(rebuilt, B, T, n_fft, hop, window, tw, frames_ws, out_offset, y_len, y, stream);
+        if (rc != AP_OK) return rc;
+        rc = ap_stft_f32(y, B, y_len, n_fft, hop, window, tw, center, pad_mode, TR, R, stream);
+        if (rc != AP_OK) return rc;
+        rc = ap_gl_project_f32(1, S, nullptr, R, TR, B * F, T, momentum, tprev, rebuilt, stream);
+        if (rc != AP_OK) return rc;
+    }
+    return ap_istft_f32(rebuilt, B, T, n_fft, hop, window, tw, frames_ws, out_offset, y_len, y, stream);
+}
+
 static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
 
 int ap_reduce_max_f32(const float *x, int64_t n, uint32_t *key_dev, void *stream) {

@@ -145,3 +145,47 @@ ap_dct_kernel(const float *x, const float *C, const float *row_scale, int64_t ou
         }
     }
 }
+
+// NumPy's default_rng(seed).uniform(low, high, n).astype(float32), element for element, on the
+// device (reference griffinlim.py:112-115 draws the initial phase with the host Generator).
+// PCG64 = 128-bit LCG (setseq) + XSL-RR output; one 64-bit output per double.  Element i is
+// produced from the state advanced by i+1 steps (O(log i) jump-ahead, pcg_advance_lcg_128), so
+// every lane is independent and the stores are coalesced.  float64 mul and add are kept
+// un-fused to match NumPy's C arithmetic (low + range * next_double) bit for bit.
+typedef unsigned __int128 ap_u128;
+
+AP_DEV ap_u128 ap_pcg64_advance(ap_u128 state, ap_u128 inc, unsigned long long delta) {
+    const ap_u128 MULT = ((ap_u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+    ap_u128 cur_mult = MULT, cur_plus = inc, acc_mult = 1, acc_plus = 0;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    return acc_mult * state + acc_plus;
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_pcg64_uniform_kernel(unsigned long long st_hi, unsigned long long st_lo, unsigned long long inc_hi,
+                        unsigned long long inc_lo, double low, double range, int64_t n, float *out) {
+#ifndef AP_HOST_EMU
+#pragma clang fp contract(off)
+#endif
+    const ap_u128 state0 = ((ap_u128)st_hi << 64) | st_lo;
+    const ap_u128 inc = ((ap_u128)inc_hi << 64) | inc_lo;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const ap_u128 s = ap_pcg64_advance(state0, inc, (unsigned long long)e + 1ULL);
+        const unsigned long long hi = (unsigned long long)(s >> 64), lo = (unsigned long long)s;
+        const unsigned long long x = hi ^ lo;
+        const unsigned rot = (unsigned)(hi >> 58);
+        const unsigned long long r = (x >> rot) | (x << ((64u - rot) & 63u));      // XSL-RR
+        const double d = (double)(r >> 11) * (1.0 / 9007199254740992.0);
+        const double v = low + range * d;
+        out[e] = (float)v;
+    }
+}

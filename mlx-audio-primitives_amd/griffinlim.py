@@ -4,10 +4,11 @@ update; parity is with the reference).
 
 Per iteration: one istft (irfft + overlap-add kernels), one stft (fused kernel) and ONE
 element-wise projection kernel that does angle -> S*exp(i angle) -> momentum -> tprev
-(the reference uses ~10 full-tensor ops for that, griffinlim.py:156-178).
-The initial phase comes from host NumPy ``default_rng(random_state)`` over the full
-(B,F,T) tensor, drawn in float64 and cast to float32, exactly as the reference does
-(griffinlim.py:112-115), so seeds reproduce.
+(the reference uses ~10 full-tensor ops for that, griffinlim.py:156-178); the whole loop is
+enqueued by one C call (``ap_griffinlim_f32``).  The initial phase is NumPy's
+``default_rng(random_state).uniform(-pi, pi, (B,F,T)).astype(float32)`` reproduced bit for bit
+ON THE DEVICE (``ap_pcg64_uniform_f32``), so seeds reproduce the reference's draw
+(griffinlim.py:112-115) without a 50 ms host RNG + PCIe copy.
 """
 
 from __future__ import annotations
@@ -20,59 +21,20 @@ from ._validation import validate_positive, validate_range
 from .stft import istft, stft
 
 
-_RNG_CHUNK = 1 << 20
-
-
-_pinned: dict[str, torch.Tensor] = {}
-
-
-def _staging(n: int, pinned: bool) -> torch.Tensor:
-    """Reusable host staging buffer (page-locking 50+ MB per call costs more than the draw)."""
-    if not pinned:
-        return torch.empty(n, dtype=torch.float32)
-    buf = _pinned.get("buf")
-    if buf is None or buf.numel() < n:
-        buf = torch.empty(max(n, 1 << 22), dtype=torch.float32).pin_memory()
-        _pinned["buf"] = buf
-    return buf[:n]
-
-
 def _random_phase(random_state, shape, device) -> torch.Tensor:
-    """uniform(-pi, pi, shape) from np.random.default_rng(random_state), float64 -> float32,
-    bit-identical to the reference's single host call (griffinlim.py:112-115).
-
-    PCG64 spends exactly one 64-bit output per double, so the stream is cut into chunks
-    whose generators are advanced to their offset and filled by a small thread pool
-    (NumPy releases the GIL while filling); each chunk is copied to the GPU asynchronously
-    from pinned memory while the next ones are still being drawn."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
+    """uniform(-pi, pi, shape) of np.random.default_rng(random_state), float64 -> float32, drawn ON
+    THE DEVICE and bit-identical to the reference's host call (griffinlim.py:112-115): the seed is
+    expanded by NumPy on the host (SeedSequence -> PCG64 state, a few hundred bytes), the stream
+    itself is produced by ap_pcg64_uniform_f32 (128-bit LCG jump-ahead + XSL-RR per element)."""
     n = int(np.prod(shape))
-    out = torch.empty(n, dtype=torch.float32, device=device)
-    if n == 0:
-        return out.reshape(shape)
-    seed_bg = np.random.default_rng(random_state).bit_generator
-    state = seed_bg.state
-    n_chunks = (n + _RNG_CHUNK - 1) // _RNG_CHUNK
-    host = _staging(n, torch.device(device).type == "cuda")
-    host_np = host.numpy()
-
-    def fill(c):
-        lo = c * _RNG_CHUNK
-        hi = min(n, lo + _RNG_CHUNK)
-        bg = np.random.PCG64()
-        bg.state = state
-        bg.advance(lo)
-        host_np[lo:hi] = np.random.Generator(bg).uniform(-np.pi, np.pi, hi - lo)   # f64 -> f32 cast
-        return lo, hi
-
-    workers = max(1, min(16, len(os.sched_getaffinity(0)), n_chunks))
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        for lo, hi in pool.map(fill, range(n_chunks)):
-            out[lo:hi].copy_(host[lo:hi], non_blocking=True)
-    if out.is_cuda:
-        torch.cuda.current_stream(out.device).synchronize()   # staging buffer is reused by the next call
+    dev = torch.device(device)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    if n:
+        st = np.random.default_rng(random_state).bit_generator.state["state"]
+        m = (1 << 64) - 1
+        _x.check(_x.lib().ap_pcg64_uniform_f32(st["state"] >> 64, st["state"] & m, st["inc"] >> 64,
+                                               st["inc"] & m, -np.pi, np.pi, n, _x.ptr(out),
+                                               _x.stream_ptr(dev)))
     return out.reshape(shape)
 
 
@@ -114,16 +76,25 @@ def griffinlim(S, n_iter: int = 32, hop_length: int | None = None, win_length: i
     else:
         raise ValueError(f"Unknown init: '{init}'. Supported: 'random', 'zeros'")
 
-    rebuilt = torch.empty((B, F, T), dtype=torch.complex64, device=dev)
-    tprev = torch.empty((B, F, T), dtype=torch.complex64, device=dev)
-    _project(0, S, angles, None, 0.0, tprev, rebuilt)          # rebuilt = tprev = S*exp(i*angles)
-    del angles
-    kw = dict(hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window,
-              center=center)
-    for _ in range(n_iter):
-        y = istft(rebuilt, length=length, **kw)
-        R = stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window,
-                 center=center, pad_mode=pad_mode)
-        _project(1, S, None, R, momentum, tprev, rebuilt)
-    y = istft(rebuilt, length=length, **kw)
+    # the whole loop is enqueued by ONE C call (no per-iteration Python / allocator work)
+    from .stft import _frame_count, _get_padded_window, _get_twiddles
+    if F != n_fft // 2 + 1:
+        raise ValueError(f"S has {F} frequency bins but n_fft={n_fft} needs {n_fft // 2 + 1}")
+    pad = n_fft // 2 if center else 0
+    natural = n_fft + (T - 1) * hop_length
+    y_len = length if length is not None else natural - 2 * pad
+    if y_len <= 0:
+        raise ValueError("griffinlim: the reconstructed signal would be empty")
+    TR = _frame_count(y_len, n_fft, hop_length, center, pad_mode)
+    win = _get_padded_window(window, win_length, n_fft, dev)
+    tw = _get_twiddles(n_fft, dev)
+    rebuilt = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
+    tprev = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
+    R = torch.empty((B, F, TR, 2), dtype=torch.float32, device=dev)
+    ws = torch.empty((B, T, n_fft), dtype=torch.float32, device=dev)
+    y = torch.empty((B, y_len), dtype=torch.float32, device=dev)
+    _x.check(_x.lib().ap_griffinlim_f32(
+        _x.ptr(S), _x.ptr(angles), B, T, int(n_fft), int(hop_length), _x.ptr(win), _x.ptr(tw),
+        int(bool(center)), _x.PAD_MODES[pad_mode], pad, y_len, TR, int(n_iter), float(momentum),
+        _x.ptr(rebuilt), _x.ptr(tprev), _x.ptr(R), _x.ptr(ws), _x.ptr(y), _x.stream_ptr(dev)))
     return y if batched else y[0]

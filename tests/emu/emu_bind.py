@@ -235,3 +235,14 @@ def resample_fft(x, num):
     _check(lib().emu_resample_fft_f32(_p(x), _i64(B), _i64(Nx), _i64(num), _p(tws[0]), _p(tws[1]),
                                       _p(tws[2]), _p(tws[3]), _p(ws), _p(out)))
     return out
+
+
+def pcg64_uniform(seed, low, high, n):
+    st = np.random.default_rng(seed).bit_generator.state["state"]
+    m = (1 << 64) - 1
+    out = np.zeros(n, np.float32)
+    u64 = ctypes.c_uint64
+    _check(lib().emu_pcg64_uniform_f32(u64(st["state"] >> 64), u64(st["state"] & m), u64(st["inc"] >> 64),
+                                       u64(st["inc"] & m), ctypes.c_double(low), ctypes.c_double(high),
+                                       _i64(n), _p(out)))
+    return out

@@ -218,6 +218,14 @@ int emu_resample_fft_f32(const float *x, int64_t B, int64_t Nx, int64_t num, con
 
 int emu_cfft_split(int64_t N, int *N1, int *N2) { return ap_cfft_split(N, N1, N2); }
 
+int emu_pcg64_uniform_f32(unsigned long long st_hi, unsigned long long st_lo, unsigned long long inc_hi,
+                          unsigned long long inc_lo, double low, double high, int64_t n, float *out) {
+    emu_launch(ap_grid_1d(n, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] {
+        ap_pcg64_uniform_kernel(st_hi, st_lo, inc_hi, inc_lo, low, high - low, n, out);
+    });
+    return AP_OK;
+}
+
 int emu_complex_unary_f32(const float *S, int64_t n, int mode, float *out) {
     emu_launch(ap_grid_1d(n, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] {
         ap_complex_unary_kernel(reinterpret_cast<const ap_float2 *>(S), n, mode, out);

@@ -191,3 +191,12 @@ def test_emu_resample_fft_matches_scipy(Nx, num, B):
     np.testing.assert_allclose(eb.resample_fft(x, num), scipy.signal.resample(x, num, axis=-1),
                                rtol=1e-4, atol=1e-5)
     assert eb.cfft_split(9001) is None and eb.cfft_split(22050) == (150, 147)
+
+
+def test_emu_pcg64_uniform_matches_numpy_bit_for_bit():
+    """Device PCG64 (128-bit LCG jump-ahead + XSL-RR) == np.random.default_rng(seed).uniform(...)"""
+    for seed, n in ((42, 100000), (7, 33), (123456789, 4097)):
+        want = np.random.default_rng(seed).uniform(-np.pi, np.pi, n).astype(np.float32)
+        np.testing.assert_array_equal(eb.pcg64_uniform(seed, -np.pi, np.pi, n), want)
+    want = np.random.default_rng(3).uniform(0.0, 1.0, 1000).astype(np.float32)
+    np.testing.assert_array_equal(eb.pcg64_uniform(3, 0.0, 1.0, 1000), want)

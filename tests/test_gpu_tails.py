@@ -190,6 +190,13 @@ def test_griffinlim_reference_thresholds(chirp_signal):
         ap.griffinlim(S, momentum=1.0)
 
 
+def test_device_pcg64_phase_matches_numpy():
+    from mlx_audio_primitives_amd.griffinlim import _random_phase
+    for seed, shape in ((42, (3, 5, 7)), (7, (2, 1025, 216)), (0, (1, 1, 1))):
+        want = np.random.default_rng(seed).uniform(-np.pi, np.pi, shape).astype(np.float32)
+        np.testing.assert_array_equal(host(_random_phase(seed, shape, "cuda")), want)
+
+
 def test_griffinlim_config3_slice():
     """cfg3 shape per clip (5 s @ 22.05 kHz, n_fft=2048 hop=512, 32 iterations), small batch."""
     g = torch.Generator(device="cuda").manual_seed(3)
