@@ -224,8 +224,8 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
 // compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
 static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels, int *G, int *lds_bytes) {
     int g;
-    if (n_fft == 400) g = 16;
-    else if (n_fft == 512) g = 16;
+    if (n_fft == 400) g = 8;
+    else if (n_fft == 512) g = 8;
     else if (n_fft == 1024) g = 8;
     else return false;
     const int nc = n_fft / 2;

@@ -63,8 +63,8 @@ static int ap_launch_ct(ApStftParams &P, int n_fft, int64_t B, void *stream, boo
         hipLaunchKernelGGL((ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN>), dim3((unsigned)grid), \
                            dim3(AP_BLOCK), lds, (hipStream_t)stream, P);                             \
     } while (0)
-    if (n_fft == 400) AP_CT_LAUNCH(200, 8, 5, 5, 16);
-    else if (n_fft == 512) AP_CT_LAUNCH(256, 16, 16, 1, 16);
+    if (n_fft == 400) AP_CT_LAUNCH(200, 8, 5, 5, 8);
+    else if (n_fft == 512) AP_CT_LAUNCH(256, 16, 16, 1, 8);
     else AP_CT_LAUNCH(512, 16, 8, 4, 8);
 #undef AP_CT_LAUNCH
     *handled = true;
