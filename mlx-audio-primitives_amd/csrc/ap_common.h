@@ -10,9 +10,17 @@
 #define AP_LDS_MAX (160 * 1024)    // gfx950 LDS per CU / max per workgroup
 #define AP_MAX_G 16                // max frames per workgroup tile
 
+// One complex float.  Under hipcc it is a clang ext-vector so that complex adds and multiplies
+// map onto gfx950's packed-f32 VALU ops (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on an
+// aligned VGPR pair = one complex); the CPU emulator (g++) sees the same layout as a struct.
+#if defined(__clang__) && !defined(AP_HOST_EMU)
+typedef float ap_float2 __attribute__((ext_vector_type(2)));
+#define AP_PACKED_COMPLEX 1
+#else
 struct __attribute__((aligned(8))) ap_float2 {
     float x, y;
 };
+#endif
 
 // Radix plan of the complex transform that backs an n_fft-point real transform.
 //   even n_fft : nc = n_fft/2 complex points (pack x[2n] + i x[2n+1]) + split pass

@@ -188,10 +188,11 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.y = P.y;
     W.window = P.window;
     W.tw = P.tw;
-    W.parts = plan + desc[6];
-    W.n_parts = desc[7];
-    W.quads = reinterpret_cast<const float *>(plan + desc[8]);
-    W.n_quads = desc[9];
+    W.parts = plan + desc[11];
+    W.n_parts = desc[12];
+    W.quads = reinterpret_cast<const float *>(plan + desc[13]);
+    W.n_quads = desc[14];
+    W.n_slots = desc[7];
     W.rowstart = plan + desc[10];
     W.out = P.out_mel;
     W.L = P.L;
@@ -209,9 +210,11 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
     W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
     W.off_wq = off; off += ap_align16(W.n_quads * 16);
-    W.off_parts = off; off += ap_align16(W.n_parts * 16);
-    W.off_partial = off; off += ap_align16(n_waves * W.n_parts * 4);
-    W.off_otile = off; off += ap_align16(n_waves * M * APW_G * 4);
+    // part descriptors beyond the APW_PASSES register-resident passes are read from LDS
+    W.off_parts = off; off += W.n_parts > 64 * APW_PASSES ? ap_align16(W.n_parts * 16) : 0;
+    W.off_partial = off; off += ap_align16(n_waves * W.n_slots * 4);
+    W.otile_stride = ((M + 27) / 32) * 32 + 4;              // >= M and = 4 (mod 32): conflict-free both ways
+    W.off_otile = off; off += ap_align16(n_waves * W.otile_stride * APW_G * 4);
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;     // does not fit: caller falls back to the generic engine
     // persistent: one 8-wave workgroup per CU; every wave strides over the tiles on its own

@@ -6,8 +6,10 @@
 #define APW_NC 1024          // complex points of the packed transform
 #define APW_G 8              // consecutive frames one wave processes before it moves to its next tile
 #define APW_WAVES 8          // waves per workgroup (2 per SIMD; they only share read-only LDS tables)
-#define APW_ROW 18           // padded row (complex) of transpose #1: conflict-free ds_read_b128
-#define APW_X_COMPLEX 1168   // complex slots of one wave's exchange buffer (>= 64*18, >= zidx(1023)+1)
+// transpose #1 layout: row r (64 rows of 16 complex) starts at complex slot 20 r + 2 (r >> 4):
+// conflict-free for both the 16 ds_write_b64 and the 8 ds_read_b128 of a frame (tools/lds_banks.py)
+#define APW_T1(r) ((r) * 20 + ((r) >> 4) * 2)
+#define APW_X_COMPLEX 1284   // complex slots of one wave's exchange buffer (>= APW_T1(63)+16, >= zidx(1023)+1)
 #define APW_PASSES 4          // contraction passes whose part descriptors live in registers (256 parts)
 #define APW_TW2_COMPLEX 72   // 4 rows x 17 (padded) of W_64^(a*c), rounded to 16 bytes
 
@@ -15,15 +17,16 @@ struct ApMelWaveParams {
     const float *y;            // (B, L)
     const float *window;       // (2048)
     const ap_float2 *tw;       // (2048) (cos, sin)(2 pi j / 2048)
-    const int32_t *parts;      // (n_parts, 4): slot, first group, n_groups, first quad
-    const float *quads;        // (n_quads, 4) filter weights of the 4 bins of a group
+    const int32_t *parts;      // (n_parts, 4) wave layout: slot, first group, n_groups (0 = idle), first quad
+    const float *quads;        // (n_quads, 4) lane-interleaved filter weights: group i at first quad + 64 i
     const int32_t *rowstart;   // (M+1) slot range of every row
     float *out;                // (B, M, T)
     int64_t L, T, tiles_per_clip, n_tiles, n_clips;
-    int hop, pad, pad_mode, n_mels, n_parts, n_quads;
+    int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots;   // n_slots: partial sums per frame
     float power;
     // LDS carve-up (bytes from the start of dynamic LDS)
     int off_tw2, off_tw1, off_win, off_wq, off_parts, off_partial, off_otile, lds_bytes;
+    int otile_stride;          // floats between the frames of a wave's [APW_G][n_mels] output tile (= 4 mod 32)
 };
 
 // ---- n_fft = 2048 STFT (complex output) wave kernel -----------------------------------

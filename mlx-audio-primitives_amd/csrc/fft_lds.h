@@ -12,14 +12,81 @@
 #define AP_DEV __device__ __forceinline__
 #endif
 
+// ---- complex arithmetic on one (re, im) register pair ---------------------------------
+// Device build: packed-f32 instructions.  The compiler folds whole-vector negations and
+// component swaps into VOP3P op_sel modifiers but not the half negations a multiply by -i or a
+// conjugate needs, so those forms are spelled as one instruction each (op_sel picks the half
+// of a source that feeds the low / high result lane, neg_lo / neg_hi negate it).
+#ifdef AP_PACKED_COMPLEX
+AP_DEV ap_float2 ap_mk(float x, float y) { ap_float2 r = {x, y}; return r; }
+AP_DEV ap_float2 ap_add(ap_float2 a, ap_float2 b) { return a + b; }
+AP_DEV ap_float2 ap_sub(ap_float2 a, ap_float2 b) { return a - b; }
+AP_DEV ap_float2 ap_scale(ap_float2 a, float s) { return a * s; }
+AP_DEV ap_float2 ap_mul2(ap_float2 a, ap_float2 b) { return a * b; }                  // per component
+AP_DEV ap_float2 ap_fma_s(ap_float2 a, float s, ap_float2 b) {                         // a*s + b
+    return __builtin_elementwise_fma(a, ap_mk(s, s), b);
+}
+AP_DEV ap_float2 ap_mul_mi(ap_float2 a) { return ap_mk(a.y, -a.x); }                  // -i a
+#define AP_PK2(name, insn)                                                    \
+    AP_DEV ap_float2 name(ap_float2 a, ap_float2 b) {                          \
+        ap_float2 d;                                                           \
+        asm(insn : "=v"(d) : "v"(a), "v"(b));                                  \
+        return d;                                                              \
+    }
+#define AP_PK3(name, insn)                                                    \
+    AP_DEV ap_float2 name(ap_float2 a, ap_float2 b, ap_float2 c) {            \
+        ap_float2 d;                                                           \
+        asm(insn : "=v"(d) : "v"(a), "v"(b), "v"(c));                          \
+        return d;                                                              \
+    }
+AP_PK2(ap_add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")   // a + (-i) b
+AP_PK2(ap_sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")   // a - (-i) b
+AP_PK2(ap_add_conj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")                              // a + conj b
+AP_PK2(ap_sub_conj, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]")                              // a - conj b
+// (b.y a.x... ) second half of a complex multiply: c + (a.y b.y, -a.x b.y)  /  c + (-a.y b.y, a.x b.y)
+AP_PK3(ap_cmul_tail_fw, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")
+AP_PK3(ap_cmul_tail_bw, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]")
+// a*h + (-i) u, a*h - (-i) u and a*h - (u.y, u.x)   (h applied per component)
+AP_PK3(ap_fma_add_mi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_hi:[0,0,1]")
+AP_PK3(ap_fma_sub_mi, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1]")
+AP_PK3(ap_fma_sub_swap, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]")
+// a * (c - i s): multiply by the forward twiddle whose table entry is (c, s)
+AP_DEV ap_float2 ap_mul_fw(ap_float2 a, ap_float2 w) { return ap_cmul_tail_fw(a, w, a * w.xx); }
+// a * (c + i s)
+AP_DEV ap_float2 ap_mul_bw(ap_float2 a, ap_float2 w) { return ap_cmul_tail_bw(a, w, a * w.xx); }
+// compile-time twiddle: the compiler keeps (c, c) and (s, -s) as scalar register pairs
+AP_DEV ap_float2 ap_mul_fw_c(ap_float2 a, float c, float s) {
+    return __builtin_elementwise_fma(a.yx, ap_mk(s, -s), a * ap_mk(c, c));
+}
+AP_DEV ap_float2 ap_mul_bw_c(ap_float2 a, float c, float s) {
+    return __builtin_elementwise_fma(a.yx, ap_mk(-s, s), a * ap_mk(c, c));
+}
+#else
 AP_DEV ap_float2 ap_mk(float x, float y) { ap_float2 r; r.x = x; r.y = y; return r; }
 AP_DEV ap_float2 ap_add(ap_float2 a, ap_float2 b) { return ap_mk(a.x + b.x, a.y + b.y); }
 AP_DEV ap_float2 ap_sub(ap_float2 a, ap_float2 b) { return ap_mk(a.x - b.x, a.y - b.y); }
-// a * (c - i s): multiply by the forward twiddle whose table entry is (c, s)
+AP_DEV ap_float2 ap_scale(ap_float2 a, float s) { return ap_mk(a.x * s, a.y * s); }
+AP_DEV ap_float2 ap_mul2(ap_float2 a, ap_float2 b) { return ap_mk(a.x * b.x, a.y * b.y); }
+AP_DEV ap_float2 ap_fma_s(ap_float2 a, float s, ap_float2 b) { return ap_mk(a.x * s + b.x, a.y * s + b.y); }
+AP_DEV ap_float2 ap_mul_mi(ap_float2 a) { return ap_mk(a.y, -a.x); }
+AP_DEV ap_float2 ap_add_mi(ap_float2 a, ap_float2 b) { return ap_mk(a.x + b.y, a.y - b.x); }
+AP_DEV ap_float2 ap_sub_mi(ap_float2 a, ap_float2 b) { return ap_mk(a.x - b.y, a.y + b.x); }
+AP_DEV ap_float2 ap_add_conj(ap_float2 a, ap_float2 b) { return ap_mk(a.x + b.x, a.y - b.y); }
+AP_DEV ap_float2 ap_sub_conj(ap_float2 a, ap_float2 b) { return ap_mk(a.x - b.x, a.y + b.y); }
+AP_DEV ap_float2 ap_cmul_tail_fw(ap_float2 a, ap_float2 w, ap_float2 c) { return ap_mk(c.x + a.y * w.y, c.y - a.x * w.y); }
+AP_DEV ap_float2 ap_cmul_tail_bw(ap_float2 a, ap_float2 w, ap_float2 c) { return ap_mk(c.x - a.y * w.y, c.y + a.x * w.y); }
+AP_DEV ap_float2 ap_fma_add_mi(ap_float2 a, ap_float2 h, ap_float2 u) { return ap_mk(a.x * h.x + u.y, a.y * h.y - u.x); }
+AP_DEV ap_float2 ap_fma_sub_mi(ap_float2 a, ap_float2 h, ap_float2 u) { return ap_mk(a.x * h.x - u.y, a.y * h.y + u.x); }
+AP_DEV ap_float2 ap_fma_sub_swap(ap_float2 a, ap_float2 h, ap_float2 u) { return ap_mk(a.x * h.x - u.y, a.y * h.y - u.x); }
 AP_DEV ap_float2 ap_mul_fw(ap_float2 a, ap_float2 w) {
     return ap_mk(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
 }
-AP_DEV ap_float2 ap_mul_mi(ap_float2 a) { return ap_mk(a.y, -a.x); }   // -i * a
+AP_DEV ap_float2 ap_mul_bw(ap_float2 a, ap_float2 w) {
+    return ap_mk(a.x * w.x - a.y * w.y, a.y * w.x + a.x * w.y);
+}
+AP_DEV ap_float2 ap_mul_fw_c(ap_float2 a, float c, float s) { return ap_mul_fw(a, ap_mk(c, s)); }
+AP_DEV ap_float2 ap_mul_bw_c(ap_float2 a, float c, float s) { return ap_mul_bw(a, ap_mk(c, s)); }
+#endif
 
 // ---- forward butterflies, natural-order outputs ---------------------------------
 AP_DEV void ap_fft2(ap_float2 &a, ap_float2 &b) {
@@ -30,11 +97,20 @@ AP_DEV void ap_fft2(ap_float2 &a, ap_float2 &b) {
 
 AP_DEV void ap_fft4(ap_float2 &a0, ap_float2 &a1, ap_float2 &a2, ap_float2 &a3) {
     ap_float2 t0 = ap_add(a0, a2), t1 = ap_sub(a0, a2);
-    ap_float2 t2 = ap_add(a1, a3), t3 = ap_mul_mi(ap_sub(a1, a3));
+    ap_float2 t2 = ap_add(a1, a3), e = ap_sub(a1, a3);
     a0 = ap_add(t0, t2);
     a2 = ap_sub(t0, t2);
-    a1 = ap_add(t1, t3);
-    a3 = ap_sub(t1, t3);
+    a1 = ap_add_mi(t1, e);
+    a3 = ap_sub_mi(t1, e);
+}
+// the same with input a2 still to be multiplied by -i (saves materialising the rotation)
+AP_DEV void ap_fft4_a2mi(ap_float2 &a0, ap_float2 &a1, ap_float2 &a2, ap_float2 &a3) {
+    ap_float2 t0 = ap_add_mi(a0, a2), t1 = ap_sub_mi(a0, a2);
+    ap_float2 t2 = ap_add(a1, a3), e = ap_sub(a1, a3);
+    a0 = ap_add(t0, t2);
+    a2 = ap_sub(t0, t2);
+    a1 = ap_add_mi(t1, e);
+    a3 = ap_sub_mi(t1, e);
 }
 
 template <int R>
@@ -56,11 +132,11 @@ struct ApButterfly<3> {
         const float S3 = 0.86602540378443864676f;
         ap_float2 t1 = ap_add(v[1], v[2]);
         ap_float2 t2 = ap_sub(v[1], v[2]);
-        ap_float2 m = ap_mk(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
-        ap_float2 s = ap_mk(S3 * t2.x, S3 * t2.y);
+        ap_float2 m = ap_fma_s(t1, -0.5f, v[0]);
+        ap_float2 s = ap_scale(t2, S3);
         v[0] = ap_add(v[0], t1);
-        v[1] = ap_mk(m.x + s.y, m.y - s.x);
-        v[2] = ap_mk(m.x - s.y, m.y + s.x);
+        v[1] = ap_add_mi(m, s);
+        v[2] = ap_sub_mi(m, s);
     }
 };
 
@@ -71,16 +147,16 @@ struct ApButterfly<5> {
         const float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;
         ap_float2 a1 = ap_add(v[1], v[4]), a2 = ap_add(v[2], v[3]);
         ap_float2 b1 = ap_sub(v[1], v[4]), b2 = ap_sub(v[2], v[3]);
-        ap_float2 m1 = ap_mk(v[0].x + C1 * a1.x + C2 * a2.x, v[0].y + C1 * a1.y + C2 * a2.y);
-        ap_float2 m2 = ap_mk(v[0].x + C2 * a1.x + C1 * a2.x, v[0].y + C2 * a1.y + C1 * a2.y);
-        ap_float2 n1 = ap_mk(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
-        ap_float2 n2 = ap_mk(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
-        v[0] = ap_mk(v[0].x + a1.x + a2.x, v[0].y + a1.y + a2.y);
+        ap_float2 m1 = ap_fma_s(a2, C2, ap_fma_s(a1, C1, v[0]));
+        ap_float2 m2 = ap_fma_s(a2, C1, ap_fma_s(a1, C2, v[0]));
+        ap_float2 n1 = ap_fma_s(b2, S2, ap_scale(b1, S1));
+        ap_float2 n2 = ap_fma_s(b2, -S1, ap_scale(b1, S2));
+        v[0] = ap_add(ap_add(v[0], a1), a2);
         // V1 = m1 - i n1, V4 = m1 + i n1, V2 = m2 - i n2, V3 = m2 + i n2
-        v[1] = ap_mk(m1.x + n1.y, m1.y - n1.x);
-        v[4] = ap_mk(m1.x - n1.y, m1.y + n1.x);
-        v[2] = ap_mk(m2.x + n2.y, m2.y - n2.x);
-        v[3] = ap_mk(m2.x - n2.y, m2.y + n2.x);
+        v[1] = ap_add_mi(m1, n1);
+        v[4] = ap_sub_mi(m1, n1);
+        v[2] = ap_add_mi(m2, n2);
+        v[3] = ap_sub_mi(m2, n2);
     }
 };
 
@@ -93,12 +169,11 @@ struct ApButterfly<8> {
         ap_fft4(e0, e1, e2, e3);
         ap_fft4(o0, o1, o2, o3);
         // W8^1 = (1-i)/sqrt2, W8^2 = -i, W8^3 = (-1-i)/sqrt2
-        o1 = ap_mk(H * (o1.x + o1.y), H * (o1.y - o1.x));
-        o2 = ap_mul_mi(o2);
-        o3 = ap_mk(H * (o3.y - o3.x), -H * (o3.x + o3.y));
+        o1 = ap_mul_fw_c(o1, H, H);
+        o3 = ap_mul_fw_c(o3, -H, H);
         v[0] = ap_add(e0, o0); v[4] = ap_sub(e0, o0);
         v[1] = ap_add(e1, o1); v[5] = ap_sub(e1, o1);
-        v[2] = ap_add(e2, o2); v[6] = ap_sub(e2, o2);
+        v[2] = ap_add_mi(e2, o2); v[6] = ap_sub_mi(e2, o2);
         v[3] = ap_add(e3, o3); v[7] = ap_sub(e3, o3);
     }
 };
@@ -117,20 +192,20 @@ struct ApButterfly<16> {
         }
         // twiddle a[r][p] *= W16^(r*p); entry (c,s) means c - i s
         // r=1: p=1 (C1,S1) p=2 (H,H) p=3 (S1,C1)
-        a[1][1] = ap_mul_fw(a[1][1], ap_mk(C1, S1));
-        a[1][2] = ap_mul_fw(a[1][2], ap_mk(H, H));
-        a[1][3] = ap_mul_fw(a[1][3], ap_mk(S1, C1));
-        // r=2: p=1 (H,H) p=2 (0,1) p=3 (-H,H)
-        a[2][1] = ap_mul_fw(a[2][1], ap_mk(H, H));
-        a[2][2] = ap_mul_mi(a[2][2]);
-        a[2][3] = ap_mul_fw(a[2][3], ap_mk(-H, H));
+        a[1][1] = ap_mul_fw_c(a[1][1], C1, S1);
+        a[1][2] = ap_mul_fw_c(a[1][2], H, H);
+        a[1][3] = ap_mul_fw_c(a[1][3], S1, C1);
+        // r=2: p=1 (H,H) p=2 (0,1) = -i, folded into the p=2 butterfly below, p=3 (-H,H)
+        a[2][1] = ap_mul_fw_c(a[2][1], H, H);
+        a[2][3] = ap_mul_fw_c(a[2][3], -H, H);
         // r=3: p=1 (S1,C1) p=2 (-H,H) p=3 m=9 -> (cos(9pi/8), sin(9pi/8)) = (-C1,-S1)
-        a[3][1] = ap_mul_fw(a[3][1], ap_mk(S1, C1));
-        a[3][2] = ap_mul_fw(a[3][2], ap_mk(-H, H));
-        a[3][3] = ap_mul_fw(a[3][3], ap_mk(-C1, -S1));
+        a[3][1] = ap_mul_fw_c(a[3][1], S1, C1);
+        a[3][2] = ap_mul_fw_c(a[3][2], -H, H);
+        a[3][3] = ap_mul_fw_c(a[3][3], -C1, -S1);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            ap_fft4(a[0][p], a[1][p], a[2][p], a[3][p]);
+            if (p == 2) ap_fft4_a2mi(a[0][p], a[1][p], a[2][p], a[3][p]);
+            else ap_fft4(a[0][p], a[1][p], a[2][p], a[3][p]);
             v[p] = a[0][p]; v[p + 4] = a[1][p]; v[p + 8] = a[2][p]; v[p + 12] = a[3][p];
         }
     }

@@ -206,6 +206,66 @@ void mel_analyse(const float *fb, int M, int F, std::vector<int> &lo, std::vecto
     int q = 0;
     for (auto &p : parts) { p.q0 = q; q += p.ng; }
 }
+
+// Wave layout of the same parts for the wave-per-frame kernels (kernels_wave.h): passes of 64
+// parts, lane l of pass p owns entry 64 p + l.  Within a pass the parts are dealt to the four
+// 16-lane groups that one ds_read_b128 serves together so that the 16-byte |X|^p groups they
+// read fall into different banks (first group index distinct modulo 16) wherever the plan
+// allows it; the weight quads are stored lane-interleaved (group i of entry e at
+// qw(e) + 64 i), which makes every weight read of a pass one contiguous 1 KiB row.
+struct MelWaveLayout {
+    std::vector<int> entry;        // 64 * passes: index into parts, or -1 (idle lane)
+    std::vector<int> qw;           // first quad of every entry
+    int n_quads = 0;
+};
+
+const int kB128Groups[4][16] = {
+    {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+
+void mel_wave_layout(const std::vector<MelPart> &parts, MelWaveLayout &L) {
+    const int n = (int)parts.size();
+    const int passes = (n + 63) / 64;
+    L.entry.assign((size_t)passes * 64, -1);
+    L.qw.assign((size_t)passes * 64, 0);
+    int block = 0;                                     // 64-quad rows used so far
+    for (int ps = 0; ps < passes; ++ps) {
+        const int first = ps * 64, last = first + 64 < n ? first + 64 : n;
+        std::vector<int> bucket[16];
+        for (int i = first; i < last; ++i) bucket[parts[i].g0 & 15].push_back(i);
+        int order[16];
+        for (int r = 0; r < 16; ++r) order[r] = r;
+        std::stable_sort(order, order + 16, [&](int a, int b) { return bucket[a].size() > bucket[b].size(); });
+        std::vector<int> grp[4];
+        int has[4][16] = {};
+        for (int oi = 0; oi < 16; ++oi) {
+            const int r = order[oi];
+            for (int idx : bucket[r]) {
+                int best = -1;
+                for (int g = 0; g < 4; ++g) {
+                    if (grp[g].size() >= 16) continue;
+                    if (best < 0 || has[g][r] < has[best][r] ||
+                        (has[g][r] == has[best][r] && grp[g].size() < grp[best].size()))
+                        best = g;
+                }
+                grp[best].push_back(idx);
+                has[best][r]++;
+            }
+        }
+        int max_ng = 0;
+        for (int g = 0; g < 4; ++g)
+            for (size_t j = 0; j < grp[g].size(); ++j) {
+                const int lane = kB128Groups[g][j];
+                L.entry[(size_t)ps * 64 + lane] = grp[g][j];
+                L.qw[(size_t)ps * 64 + lane] = block * 64 + lane;
+                if (parts[grp[g][j]].ng > max_ng) max_ng = parts[grp[g][j]].ng;
+            }
+        block += max_ng;
+    }
+    L.n_quads = block * 64;
+}
 }  // namespace
 
 int64_t ap_mel_plan_words(const float *fb, int n_mels, int n_bins) {
@@ -215,7 +275,10 @@ int64_t ap_mel_plan_words(const float *fb, int n_mels, int n_bins) {
     mel_analyse(fb, n_mels, n_bins, lo, len, parts);
     int64_t quads = 0;
     for (auto &p : parts) quads += p.ng;
-    return 2 * (int64_t)n_mels + 4 * (int64_t)parts.size() + 4 * quads + (int64_t)n_mels + 1 + 8;
+    MelWaveLayout L;
+    mel_wave_layout(parts, L);
+    return 2 * (int64_t)n_mels + 4 * (int64_t)parts.size() + 4 * quads + (int64_t)n_mels + 1 + 8 +
+           4 * (int64_t)L.entry.size() + 4 * (int64_t)L.n_quads + 8;
 }
 
 int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int32_t *desc) {
@@ -239,6 +302,11 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     const int64_t off_parts = off; off += 4 * (int64_t)parts.size();
     const int64_t off_quads = off; off += 4 * quads;
     const int64_t off_rs = off; off += (int64_t)M + 1;
+    off += off & 3 ? 4 - (off & 3) : 0;
+    MelWaveLayout WL;
+    mel_wave_layout(parts, WL);
+    const int64_t off_wparts = off; off += 4 * (int64_t)WL.entry.size();
+    const int64_t off_wquads = off; off += 4 * (int64_t)WL.n_quads;
     for (int m = 0; m < M; ++m) { plan[off_lo + m] = lo[m]; plan[off_len + m] = len[m]; }
     bool parts_ok = true;
     // rowstart[m] .. rowstart[m+1]: the row-major slots that hold row m's partial sums
@@ -262,6 +330,20 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
                 wq[4 * (size_t)(p.q0 + g) + e] = k < F ? fb[(size_t)p.row * F + k] : 0.0f;
             }
     }
+    float *wwq = reinterpret_cast<float *>(plan + off_wquads);
+    for (size_t e = 0; e < WL.entry.size(); ++e) {
+        if (WL.entry[e] < 0) continue;                       // idle lane: all-zero descriptor (ng = 0)
+        const MelPart &p = parts[WL.entry[e]];
+        plan[off_wparts + 4 * e + 0] = p.slot;
+        plan[off_wparts + 4 * e + 1] = p.g0;
+        plan[off_wparts + 4 * e + 2] = p.ng;
+        plan[off_wparts + 4 * e + 3] = WL.qw[e];
+        for (int g = 0; g < p.ng; ++g)
+            for (int c = 0; c < 4; ++c) {
+                const int k = 4 * (p.g0 + g) + c;
+                wwq[4 * ((size_t)WL.qw[e] + 64 * (size_t)g) + c] = k < F ? fb[(size_t)p.row * F + k] : 0.0f;
+            }
+    }
     desc[0] = AP_PLAN_BANDED | (parts_ok ? AP_PLAN_PARTS : 0);
     desc[1] = M;
     desc[2] = F;
@@ -273,7 +355,10 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     desc[8] = (int32_t)off_quads;
     desc[9] = (int32_t)quads;
     desc[10] = (int32_t)off_rs;
-    desc[11] = 0;
+    desc[11] = (int32_t)off_wparts;
+    desc[12] = (int32_t)WL.entry.size();
+    desc[13] = (int32_t)off_wquads;
+    desc[14] = (int32_t)WL.n_quads;
     return AP_OK;
 }
 

@@ -61,14 +61,14 @@ struct __attribute__((aligned(16))) ap_int4 { int x, y, z, w; };
 // (tools/lds_banks.py)
 AP_DEV int apw_zidx(int k) { return k + 4 * (k >> 8); }
 
-// |X'|^p of X' = 2X with the exponent class fixed at compile time (2: power 2, 1: power 1,
+// |X|^p with the exponent class fixed at compile time (2: power 2, 1: power 1,
 // 0: anything else) so no powf code sits in the power-2 instruction stream.
 template <int PMODE>
 AP_DEV float apw_pow2x(float re, float im, float power) {
     const float p2 = re * re + im * im;
-    if (PMODE == 2) return 0.25f * p2;
-    if (PMODE == 1) return 0.5f * sqrtf(p2);
-    return powf(0.5f * sqrtf(p2), power);
+    if (PMODE == 2) return p2;
+    if (PMODE == 1) return sqrtf(p2);
+    return powf(sqrtf(p2), power);
 }
 
 #ifdef AP_HOST_EMU
@@ -96,9 +96,10 @@ AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
 struct ApwLane {
     int lane, qa, qd, k1p;
     float s1, s2;
-    bool rot;
+    ap_float2 rotw;                // (1, 0), or (0, 1) = -i on the quad's lane 3
     const ap_float2 *tw2row;
-    ap_float2 tws0;
+    ap_float2 tws0h;               // W_2048^lane / 2; bins k = lane + 64 r add W_32^r
+    ap_float2 half, halfc;         // (1/2, 1/2), (1/2, -1/2)
 };
 
 AP_DEV ApwLane apw_lane_init(int lane, const ap_float2 *TW2, const ap_float2 *tw) {
@@ -107,11 +108,13 @@ AP_DEV ApwLane apw_lane_init(int lane, const ap_float2 *TW2, const ap_float2 *tw
     c.qa = lane & 3;                              // position in the quad
     c.s1 = c.qa < 2 ? 1.0f : -1.0f;               // radix-4 stage-1 sign
     c.s2 = (c.qa & 1) ? -1.0f : 1.0f;             // radix-4 stage-2 sign
-    c.rot = c.qa == 3;                            // lane 3 multiplies by -i between stages
+    c.rotw = c.qa == 3 ? ap_mk(0.0f, 1.0f) : ap_mk(1.0f, 0.0f);   // lane 3 multiplies by -i between stages
     c.qd = ((c.qa & 1) << 1) | (c.qa >> 1);       // output digit held by this lane
     c.k1p = lane >> 2;
     c.tw2row = TW2 + c.qa * 17;
-    c.tws0 = tw[lane];                            // W_2048^lane; bins k = lane + 64 r add W_32^r
+    c.tws0h = ap_scale(tw[lane], 0.5f);
+    c.half = ap_mk(0.5f, 0.5f);
+    c.halfc = ap_mk(0.5f, -0.5f);
     return c;
 }
 
@@ -140,27 +143,40 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
     {   // transpose #1: (n0 = a + 4b, k1) -> lane (k1, a), register b
         const int a = lane & 3, bq = lane >> 2;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) X[(k * 4 + a) * APW_ROW + bq] = v[k];
+        for (int k = 0; k < 16; ++k) X[APW_T1(k * 4 + a) + bq] = v[k];
     }
     AP_WAVE_SYNC();
     ap_float2 t2[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = X[lane * APW_ROW + i];
+    for (int i = 0; i < 16; ++i) v[i] = X[APW_T1(lane) + i];
 #pragma unroll
     for (int cc = 1; cc < 16; ++cc) t2[cc] = c.tw2row[cc];         // W_64^(a*c)
     AP_WAVE_SYNC();
     ApButterfly<16>::run(v);
 #pragma unroll
     for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);
-    // radix-4 across the quad (DIF), outputs in bit-reversed lanes
+    // radix-4 across the quad (DIF), outputs in bit-reversed lanes.  Stage by stage over 8
+    // values at a time so that dependent instructions sit 8 apart (a DPP read of a fresh VALU
+    // result otherwise costs wait states).
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-        float tx = ap_quad_xor2(v[cc].x) + c.s1 * v[cc].x;
-        float ty = ap_quad_xor2(v[cc].y) + c.s1 * v[cc].y;
-        const float rx = c.rot ? ty : tx;          // * (-i) on lane 3
-        const float ry = c.rot ? -tx : ty;
-        v[cc].x = ap_quad_xor1(rx) + c.s2 * rx;
-        v[cc].y = ap_quad_xor1(ry) + c.s2 * ry;
+    for (int h = 0; h < 16; h += 8) {
+        ap_float2 p[8];
+        AP_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = ap_mk(ap_quad_xor2(v[h + i].x), ap_quad_xor2(v[h + i].y));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[h + i] = ap_fma_s(v[h + i], c.s1, p[i]);
+        AP_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = ap_scale(v[h + i], c.rotw.x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[h + i] = ap_cmul_tail_fw(v[h + i], c.rotw, p[i]);   // * (-i) on lane 3
+        AP_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = ap_mk(ap_quad_xor1(v[h + i].x), ap_quad_xor1(v[h + i].y));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[h + i] = ap_fma_s(v[h + i], c.s2, p[i]);
+        AP_SCHED_FENCE();
     }
     // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d (skipped when the caller stores
     // v[cc] = Z[k1p + 16 cc + 256 qd] itself)
@@ -171,10 +187,12 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
     }
 }
 
-// paired real split from Z in X: xk[r] = 2 X[lane + 64 r], xm[r] = 2 X[1024 - lane - 64 r],
-// zh = Z[512] (X[512] = conj Z[512]).  All of Z is read before anything else touches X.
-//   a2 = Z[k] + conj Z[1024-k], d2 = Z[k] - conj Z[1024-k], u = W^k d2
-//   2X[k] = (a2.x + u.y, a2.y - u.x),  2X[1024-k] = (a2.x - u.y, -a2.y - u.x)
+// paired real split from Z in X: xk[r] = X[lane + 64 r], xm[r] = X[1024 - lane - 64 r] (CONJ = true)
+// or its conjugate (CONJ = false, enough for |X|), zh = Z[512] (X[512] = conj Z[512]).  All of Z
+// is read before anything else touches X.
+//   a = Z[k] + conj Z[1024-k], d = Z[k] - conj Z[1024-k], u = (W^k / 2) d
+//   X[k] = a/2 + (-i) u,  conj X[1024-k] = a/2 - (-i) u
+template <bool CONJ>
 AP_DEV void apw_split(const ap_float2 *X, const ApwLane &c, ap_float2 (&xk)[8], ap_float2 (&xm)[8],
                       ap_float2 &zh) {
     ap_float2 zk[8], zm[8];
@@ -188,15 +206,13 @@ AP_DEV void apw_split(const ap_float2 *X, const ApwLane &c, ap_float2 (&xk)[8], 
     AP_WAVE_SYNC();
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const float ax = zk[r].x + zm[r].x, ay = zk[r].y - zm[r].y;
-        const float dx = zk[r].x - zm[r].x, dy = zk[r].y + zm[r].y;
-        // (cos, sin) of angle(lane) + angle(64 r): angle addition with constants
-        const float wc = c.tws0.x * APW_C32(r) - c.tws0.y * APW_S32(r);
-        const float ws = c.tws0.y * APW_C32(r) + c.tws0.x * APW_S32(r);
-        const float ux = wc * dx + ws * dy;
-        const float uy = wc * dy - ws * dx;
-        xk[r] = ap_mk(ax + uy, ay - ux);
-        xm[r] = ap_mk(ax - uy, -ay - ux);
+        const ap_float2 a = ap_add_conj(zk[r], zm[r]);
+        const ap_float2 d = ap_sub_conj(zk[r], zm[r]);
+        // (cos, sin)/2 of angle(lane) + angle(64 r): angle addition with constants
+        const ap_float2 w = r == 0 ? c.tws0h : ap_mul_bw_c(c.tws0h, APW_C32(r), APW_S32(r));
+        const ap_float2 u = ap_mul_fw(d, w);
+        xk[r] = ap_fma_add_mi(a, c.half, u);
+        xm[r] = CONJ ? ap_fma_sub_swap(a, c.halfc, u) : ap_fma_sub_mi(a, c.half, u);
     }
 }
 
@@ -213,8 +229,8 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
     const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // [1024] pairs
     const ap_float4 *WQ = reinterpret_cast<const ap_float4 *>(ap_smem + P.off_wq);     // [n_quads]
     const ap_int4 *PART = reinterpret_cast<const ap_int4 *>(ap_smem + P.off_parts);    // [n_parts]
-    float *partial = reinterpret_cast<float *>(ap_smem + P.off_partial) + wave * P.n_parts;   // this wave's
-    float *otile = reinterpret_cast<float *>(ap_smem + P.off_otile) + wave * P.n_mels * APW_G;  // [M][APW_G]
+    float *partial = reinterpret_cast<float *>(ap_smem + P.off_partial) + wave * P.n_slots;   // this wave's
+    float *otile = reinterpret_cast<float *>(ap_smem + P.off_otile) + wave * P.otile_stride * APW_G;  // [APW_G][stride]
     const int M = P.n_mels;
 
     // ---------------- workgroup tables in LDS (once; the only workgroup barrier) ------
@@ -223,7 +239,8 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
         ap_float4 *wq = reinterpret_cast<ap_float4 *>(ap_smem + P.off_wq);
         ap_int4 *part = reinterpret_cast<ap_int4 *>(ap_smem + P.off_parts);
         for (int i = tid; i < P.n_quads; i += nt) wq[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
-        for (int i = tid; i < P.n_parts; i += nt) part[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
+        if (P.n_parts > 64 * APW_PASSES)
+            for (int i = tid; i < P.n_parts; i += nt) part[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
         apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
                         reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
                         reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid, nt);
@@ -290,7 +307,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
 #pragma unroll
                 for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ap_mk(raw[j].x * w[j].x, raw[j].y * w[j].y);
+                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], w[j]);
             }
             // issue the next frame's loads only AFTER the old samples are consumed: otherwise the
             // compiler hoists them and then has to wait vmcnt(0) for them inside this frame
@@ -300,14 +317,14 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             apw_forward(v, X, TW1, lc);
             {
                 ap_float2 xk[8], xm[8], zh;
-                apw_split(X, lc, xk, xm, zh);           // all of Z is in registers: the plane overwrites it
+                apw_split<false>(X, lc, xk, xm, zh);    // all of Z is in registers: the plane overwrites it
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int k = lane + 64 * r;
                     pp[k] = apw_pow2x<PMODE>(xk[r].x, xk[r].y, P.power);
                     pp[APW_NC - k] = apw_pow2x<PMODE>(xm[r].x, xm[r].y, P.power);
                 }
-                if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(2.0f * zh.x, 2.0f * zh.y, P.power);
+                if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(zh.x, zh.y, P.power);
             }
             AP_WAVE_SYNC();
             // ---- mel contraction of this frame by its own wave (no workgroup barrier) ----
@@ -322,7 +339,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
                 ap_float4 w[4], q[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (i < pd.z) { w[i] = wq[i]; q[i] = pq[i]; }
+                    if (i < pd.z) { w[i] = wq[64 * i]; q[i] = pq[i]; }
                 float acc = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -342,13 +359,13 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
                     const ap_float4 *wq = WQ + pd.w;
                     float acc = 0.0f;
                     for (int i = 0; i < pd.z; ++i) {
-                        const ap_float4 w = wq[i], q = pq[i];
+                        const ap_float4 w = wq[64 * i], q = pq[i];
                         acc = fmaf(w.x, q.x, acc);
                         acc = fmaf(w.y, q.y, acc);
                         acc = fmaf(w.z, q.z, acc);
                         acc = fmaf(w.w, q.w, acc);
                     }
-                    partial[pd.x] = acc;
+                    if (pd.z > 0) partial[pd.x] = acc;
                 }
             }
             AP_WAVE_SYNC();
@@ -360,21 +377,21 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
                 if (row < M) {
                     float sum = 0.0f;
                     for (int j = rs0[i]; j < rs1[i]; ++j) sum += partial[j];
-                    otile[row * APW_G + g] = sum;
+                    otile[g * P.otile_stride + row] = sum;
                 }
             }
             for (int row = lane + 128; row < M; row += 64) {       // n_mels > 128
                 const int a0 = P.rowstart[row], a1 = P.rowstart[row + 1];
                 float sum = 0.0f;
                 for (int j = a0; j < a1; ++j) sum += partial[j];
-                otile[row * APW_G + g] = sum;
+                otile[g * P.otile_stride + row] = sum;
             }
             AP_WAVE_SYNC();
         }
         // ---- store the tile: APW_G consecutive lanes write one 32-byte row segment of (B,M,T) --
         for (int e = lane; e < M * APW_G; e += 64) {
             const int m = e / APW_G, g = e - m * APW_G;
-            if (g < Gt) ob[(int64_t)m * P.T + g] = otile[e];
+            if (g < Gt) ob[(int64_t)m * P.T + g] = otile[g * P.otile_stride + m];
         }
         AP_WAVE_SYNC();
         f += Gt;
@@ -439,14 +456,14 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
 #pragma unroll
             for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = ap_mk(raw[j].x * w[j].x, raw[j].y * w[j].y);
+            for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], w[j]);
         }
         AP_SCHED_FENCE();
         if (group + gridDim.x < P.n_groups) load_frame(group + gridDim.x);   // next group's frame
         AP_SCHED_FENCE();
         apw_forward(v, X, TW1, lc);
         ap_float2 xk[8], xm[8], zh;
-        apw_split(X, lc, xk, xm, zh);
+        apw_split<true>(X, lc, xk, xm, zh);
 
         // ---- transposed store: chunk c holds r = 2c, 2c+1 (bins 64r+lane and 1024-64r-lane) ----
 #pragma unroll
@@ -455,8 +472,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int r = 2 * c + rr;
-                buf[(rr * 128 + lane) * APS_OB_ROW + wave] = ap_mk(0.5f * xk[r].x, 0.5f * xk[r].y);
-                buf[(rr * 128 + 64 + lane) * APS_OB_ROW + wave] = ap_mk(0.5f * xm[r].x, 0.5f * xm[r].y);
+                buf[(rr * 128 + lane) * APS_OB_ROW + wave] = xk[r];
+                buf[(rr * 128 + 64 + lane) * APS_OB_ROW + wave] = xm[r];
             }
             if (c == 3 && lane == 0) buf[256 * APS_OB_ROW + wave] = ap_mk(zh.x, -zh.y);   // X[512] = conj Z[512]
             __syncthreads();
@@ -500,7 +517,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     __syncthreads();
     const int F = APW_NC + 1;
-    const float scale = 1.0f / 2048.0f;
+    const float scale = 1.0f / 1024.0f;    // 1/n_fft, and the merge above works at half scale
 
     for (int64_t group = blockIdx.x; group < P.n_groups; group += gridDim.x) {
         const int64_t b = group / P.groups_per_clip;
@@ -529,29 +546,24 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
             }
             if (c == 3) xh = buf[256 * APS_OB_ROW + wave];
         }
-        // ---- Hermitian merge: conj(Z[k]) and conj(Z[1024-k]) of the packed inverse ----------
-        //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = W^-k d
-        //   conj Z[k] = (a.x - o.y, -(a.y + o.x)),  conj Z[1024-k] = (a.x + o.y, a.y - o.x)
+        // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[1024-k]) / 2 of the packed inverse -----
+        //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = (W^-k / 2) d
+        //   conj Z[k] / 2 = conj(a/2 + i o),  conj Z[1024-k] / 2 = a/2 - i o
         ap_float2 v[16];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             ap_float2 a_k = xk[r], a_m = xm[r];
             if (r == 0 && lane == 0) { a_k.y = 0.0f; a_m.y = 0.0f; }      // DC / Nyquist imaginary parts ignored
-            const float ax = a_k.x + a_m.x, ay = a_k.y - a_m.y;
-            const float dx = a_k.x - a_m.x, dy = a_k.y + a_m.y;
-            const float wc = lc.tws0.x * APW_C32(r) - lc.tws0.y * APW_S32(r);
-            const float ws = lc.tws0.y * APW_C32(r) + lc.tws0.x * APW_S32(r);
-            const float ox = wc * dx - ws * dy, oy = wc * dy + ws * dx;     // W^-k = (c, +s)
-            v[r] = ap_mk(ax - oy, -(ay + ox));                               // index lane + 64 r
+            const ap_float2 a = ap_add_conj(a_k, a_m);
+            const ap_float2 d = ap_sub_conj(a_k, a_m);
+            const ap_float2 w = r == 0 ? lc.tws0h : ap_mul_bw_c(lc.tws0h, APW_C32(r), APW_S32(r));
+            const ap_float2 o = ap_mul_bw(d, w);                           // W^-k = (c, +s)
+            v[r] = ap_fma_sub_swap(a, lc.halfc, o);                         // index lane + 64 r
             // index 1024 - k belongs to lane 64 - lane (register 15 - r): exchange through LDS
             const int km = (APW_NC - (lane + 64 * r)) & (APW_NC - 1);
-            if (!(r == 0 && lane == 0)) X[apw_zidx(km)] = ap_mk(ax + oy, ay - ox);
+            if (!(r == 0 && lane == 0)) X[apw_zidx(km)] = ap_fma_add_mi(a, lc.half, o);
         }
-        if (lane == 0) {    // bin 512 pairs with itself: conj Z[512] = (2 re, 2 im) of ... see kernels_generic.h
-            const float ax = 2.0f * xh.x, dy = 2.0f * xh.y;                  // a = (2re, 0), d = (0, 2im)
-            // W^-512 = (0, 1): o = (-dy, 0)
-            X[apw_zidx(APW_NC / 2)] = ap_mk(ax, dy);                         // (a.x - o.y, -(a.y + o.x)) = (2re, 2im)
-        }
+        if (lane == 0) X[apw_zidx(APW_NC / 2)] = xh;    // bin 512 pairs with itself: conj Z[512] / 2 = X[512]
         AP_WAVE_SYNC();
 #pragma unroll
         for (int j = 8; j < 16; ++j) v[j] = X[apw_zidx(lane + 64 * j)];
@@ -563,7 +575,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) {
                 const int n = lc.k1p + 16 * cc + 256 * lc.qd;
-                *reinterpret_cast<ap_float2 *>(dst + 2 * n) = ap_mk(v[cc].x * scale, -v[cc].y * scale);
+                *reinterpret_cast<ap_float2 *>(dst + 2 * n) = ap_mul2(v[cc], ap_mk(scale, -scale));
             }
         }
     }
