@@ -260,6 +260,7 @@ static inline int ap_prepare_stft_wave(ApStftWaveParams &W, const ApStftParams &
     W.off_ob = off; off += ap_align16(2 * APS_OB_ROWS * APS_OB_ROW * (int)sizeof(ap_float2));
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;
+    if (P.T > (1 << 20)) return 1;                        // 32-bit row offsets (1024 T complex) in the store phase
     int64_t g = W.n_groups < 256 ? W.n_groups : 256;      // persistent: one workgroup per CU
     *grid = (int)g;
     return AP_OK;

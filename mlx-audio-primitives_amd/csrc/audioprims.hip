@@ -2,6 +2,7 @@
 // (ap_launch.h), then enqueue the gfx950 kernels.  Nothing here allocates device
 // memory or synchronises.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>

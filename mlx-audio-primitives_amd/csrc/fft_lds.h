@@ -12,6 +12,16 @@
 #define AP_DEV __device__ __forceinline__
 #endif
 
+// Workgroup barrier for kernels whose threads only ever communicate through LDS: wait for this
+// wave's LDS traffic, then s_barrier.  __syncthreads() would also drain every outstanding global
+// store (vmcnt(0), the workgroup-scope release) and expose the full HBM write latency at each
+// barrier of a store-heavy kernel.
+#ifdef AP_HOST_EMU
+#define AP_LDS_BARRIER() __syncthreads()
+#else
+#define AP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 // ---- complex arithmetic on one (re, im) register pair ---------------------------------
 // Device build: packed-f32 instructions.  The compiler folds whole-vector negations and
 // component swaps into VOP3P op_sel modifiers but not the half negations a multiply by -i or a
@@ -290,7 +300,7 @@ AP_DEV ap_float2 *ap_fft_tile(ap_float2 *a, ap_float2 *b, const ApFftPlan &pl, c
             default: ap_stockham_pass_prime(src, dst, pl, R, Ns, tw, G, fstride, tid, nthreads); break;
         }
         Ns *= R;
-        __syncthreads();
+        AP_LDS_BARRIER();
         ap_float2 *t = src; src = dst; dst = t;
     }
     return src;

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_cfft_strided_kernel(ApCfftParams 
         }
         bufA[g * fstride + i] = z;
     }
-    __syncthreads();
+    AP_LDS_BARRIER();
     ap_float2 *Z = ap_fft_tile(bufA, bufB, pl, P.tw, G, fstride, tid, nthreads);
 
     float *out_r = reinterpret_cast<float *>(P.out) + sig * P.out_batch;

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
         for (int i = tid; i < P.n_parts; i += AP_BLOCK) partl[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
         for (int i = tid; i <= P.n_mels; i += AP_BLOCK) rsl[i] = P.rowstart[i];
     }
-    __syncthreads();
+    AP_LDS_BARRIER();
 
     const int64_t n_tiles = P.tiles_per_clip * P.n_clips;
     // the samples of a tile are fetched one tile ahead into registers (NI pairs per thread), so
@@ -109,16 +109,16 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
 #ifndef AP_HOST_EMU
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        __syncthreads();
+        AP_LDS_BARRIER();
         ap_stockham_pass_ct<R0, NC, 1, G>(bufA, bufB, twl, tid);
-        __syncthreads();
+        AP_LDS_BARRIER();
         ap_stockham_pass_ct<R1, NC, R0, G>(bufB, bufA, twl, tid);
-        __syncthreads();
+        AP_LDS_BARRIER();
         ap_float2 *Z = bufA;
         ap_float2 *other = bufB;
         if (R2 > 1) {
             ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G>(bufA, bufB, twl, tid);
-            __syncthreads();
+            AP_LDS_BARRIER();
             Z = bufB;
             other = bufA;
         }
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                 const int g = item - k * G;
                 if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split(Z + g * FS, NC, k, twl);
             }
-            __syncthreads();
+            AP_LDS_BARRIER();
         } else {
             float *Pw = reinterpret_cast<float *>(other);
             constexpr int PS = (2 * FS) & ~3;                  // 16-byte aligned planes, >= F + 3
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                     if (k < PS) Pw[g * PS + k] = 0.0f;
                 }
             }
-            __syncthreads();
+            AP_LDS_BARRIER();
             if (P.n_parts > 0) {
                 // plan-based banded contraction, everything from LDS (16-byte reads)
                 for (int item = tid; item < P.n_parts * G; item += AP_BLOCK) {
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                     }
                     partial[pd.x * G + g] = acc;
                 }
-                __syncthreads();
+                AP_LDS_BARRIER();
                 for (int item = tid; item < P.n_mels * G; item += AP_BLOCK) {
                     const int m = item / G;
                     const int g = item - m * G;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                     }
                 }
             }
-            __syncthreads();
+            AP_LDS_BARRIER();
         }
     }
 }

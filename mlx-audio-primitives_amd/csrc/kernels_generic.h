@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_generic_kernel(ApStftParams 
         }
         bufA[g * fstride + c] = z;
     }
-    __syncthreads();
+    AP_LDS_BARRIER();
 
     ap_float2 *Z = ap_fft_tile(bufA, bufB, pl, P.tw, G, fstride, tid, nthreads);
     const int F = P.n_bins;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_generic_kernel(ApStftParams 
             const ap_float2 X = pl.even ? ap_rfft_split(Zg, nc, k, P.tw) : Zg[k];
             Pw[g * pstride + k] = ap_pow_mag(X.x, X.y, P.power);
         }
-        __syncthreads();
+        AP_LDS_BARRIER();
         // banded contraction: zeros outside [lo, lo+len) contribute exactly 0
         for (int item = tid; item < P.n_mels * G; item += nthreads) {
             const int m = item / G;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_irfft_generic_kernel(ApIrfftParam
         }
         bufA[g * fstride + k] = zc;
     }
-    __syncthreads();
+    AP_LDS_BARRIER();
 
     ap_float2 *Y = ap_fft_tile(bufA, bufB, pl, P.tw, G, fstride, tid, nthreads);
     const float scale = 1.0f / (float)n;
@@ -294,7 +294,7 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
         const int64_t g = s0 + i;
         xs[ap_rsp_pad(i)] = (g >= 0 && g < L) ? xb[g] : 0.0f;
     }
-    __syncthreads();
+    AP_LDS_BARRIER();
     // thread -> outputs o0 + R*tid + r; its window starts at xs[R*down*tid]
     float acc[AP_RSP_R];
 #pragma unroll

@@ -20,6 +20,10 @@ STFT_CASES = [
     # n_fft, hop, L, B, pad_mode, center   (radix plans: 16*16, 16*16*4, 8*5*5, 8*4, 3*5, 3*3*3, 11, 7*11, 16*16*16)
     (512, 128, 4000, 2, "constant", True),
     (2048, 512, 6000, 1, "reflect", True),
+    # 3 clips x 22 frames = 9 groups on 2 workgroups: carried (sector-aligned) row windows, a clip
+    # change inside a workgroup's stretch and a stretch that ends mid-clip
+    (2048, 512, 10752, 3, "constant", True),
+    (2048, 512, 9300, 2, "constant", False),
     (400, 160, 3000, 3, "constant", True),
     (64, 16, 500, 1, "edge", True),
     (30, 7, 400, 2, "constant", False),

@@ -52,6 +52,19 @@ def test_stft_grid(random_signal, n_fft, hop):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,L,pad_mode", [(40, 44100, "constant"), (24, 60001, "reflect"), (300, 9000, "constant")])
+def test_stft_2048_many_groups(B, L, pad_mode):
+    """n_fft=2048 wave kernel with more 8-frame groups than workgroups: every workgroup walks a
+    stretch of groups (sector-aligned, carried row windows), stretches cross clip boundaries and
+    end mid-clip; odd and even frame counts."""
+    rng = np.random.default_rng(B)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ap.stft(dev(y), n_fft=2048, hop_length=512, pad_mode=pad_mode)
+    R = ao.stft(y, n_fft=2048, hop_length=512, pad_mode=pad_mode)
+    assert S.shape == R.shape
+    np.testing.assert_allclose(host(S), R, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("pad_mode", ["constant", "reflect", "edge"])
 @pytest.mark.parametrize("center", [True, False])
 def test_stft_pad_modes(random_signal, pad_mode, center):

@@ -1,0 +1,29 @@
+"""Run one operator a few times on the headline-sized batch (for rocprofv3 passes).
+usage: python3 tools/run_op.py {stft|istft|mel|whisper|gl} [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mlx_audio_primitives_amd as ap
+
+op = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+g = torch.Generator(device="cuda").manual_seed(1)
+if op == "whisper":
+    y = torch.randn((256, 160000), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.melspectrogram(y, sr=16000, n_fft=400, hop_length=160, n_mels=80)
+elif op == "gl":
+    y = torch.randn((64, 110250), device="cuda", generator=g) * 0.1
+    S = ap.magnitude(ap.stft(y))
+    fn = lambda: ap.griffinlim(S, n_iter=4, hop_length=512, length=110250)
+else:
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    if op == "stft":
+        fn = lambda: ap.stft(y, n_fft=2048, hop_length=512)
+    elif op == "istft":
+        S = ap.stft(y, n_fft=2048, hop_length=512)
+        fn = lambda: ap.istft(S, hop_length=512, length=220500)
+    else:
+        fn = lambda: ap.melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+for _ in range(reps):
+    fn()
+torch.cuda.synchronize()
