@@ -84,16 +84,20 @@ static inline int ap_prepare_resample_poly(const float *x, int64_t B, int64_t L,
     return AP_OK;
 }
 
-// LDS-tiled decimator (up == 1): eligibility and dynamic LDS size
-static inline bool ap_resample_decim_eligible(int up, int down, int n_taps, int *lds_bytes) {
+// LDS-tiled decimator (up == 1): eligibility, output quad-groups per thread and dynamic LDS size.
+// Q = 1 measured fastest on MI355X (0.95 ms against 1.67 ms with Q = 4 for 1024 x 480 000 -> 160 000:
+// the bigger span leaves 3 workgroups per CU and the staging phase is no longer hidden).
+static inline bool ap_resample_decim_eligible(int up, int down, int n_taps, int *Q, int *lds_bytes) {
     if (up != 1 || down < 2 || down > 8) return false;
     const int R = 4;
     const int margin = down * (R - 1);
-    const int n_h = (n_taps + 2 * margin + 3) & ~3;
-    const int span = AP_BLOCK * R * down + n_taps - 1;
-    const int xs = span + (span >> 5) + 1;
-    *lds_bytes = (n_h + xs) * (int)sizeof(float);
-    return *lds_bytes <= 64 * 1024;
+    const int steps = (n_taps + margin + 3) & ~3;
+    for (int q = 1; q >= 1; q >>= 1) {
+        const int span = AP_BLOCK * R * q * down + steps;
+        const int bytes = (steps * R + span) * (int)sizeof(float);
+        if (bytes <= 64 * 1024) { *Q = q; *lds_bytes = bytes; return true; }
+    }
+    return false;
 }
 
 static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, int64_t L, int n_fft,

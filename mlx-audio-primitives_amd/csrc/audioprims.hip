@@ -224,15 +224,16 @@ int ap_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down,
     int64_t bpr;
     int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
     if (rc != AP_OK) return rc;
-    int lds = 0;
-    if (ap_resample_decim_eligible(up, down, n_taps, &lds)) {
-        const int64_t per_block = AP_BLOCK * 4;
-        const int64_t bpr4 = (n_out + per_block - 1) / per_block;
-        if (bpr4 * B <= kApMaxGrid) {
-            rc = ap_allow_lds(ap_resample_decim_kernel, lds);
+    int lds = 0, Q = 0;
+    if (ap_resample_decim_eligible(up, down, n_taps, &Q, &lds)) {
+        const int64_t per_block = AP_BLOCK * 4 * Q;
+        const int64_t bprq = (n_out + per_block - 1) / per_block;
+        if (bprq * B <= kApMaxGrid) {
+            auto kern = Q == 4 ? ap_resample_decim_kernel<4> : Q == 2 ? ap_resample_decim_kernel<2> : ap_resample_decim_kernel<1>;
+            rc = ap_allow_lds(kern, lds);
             if (rc != AP_OK) return rc;
-            hipLaunchKernelGGL(ap_resample_decim_kernel, dim3((unsigned)(bpr4 * B)), dim3(AP_BLOCK), lds,
-                               (hipStream_t)stream, x, L, down, taps, n_taps, n_pre_remove, n_out, bpr4, out);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(bprq * B)), dim3(AP_BLOCK), lds,
+                               (hipStream_t)stream, x, L, down, taps, n_taps, n_pre_remove, n_out, bprq, out);
             return ap_check_launch("ap_resample_poly_f32(decim)");
         }
     }

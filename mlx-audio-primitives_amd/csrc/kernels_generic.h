@@ -262,12 +262,25 @@ ap_resample_poly_kernel(const float *x, int64_t L, int up, int down, const float
 // Decimating case (up == 1, e.g. 48 kHz -> 16 kHz) of the same filter, LDS-tiled and register
 // blocked: a workgroup stages the contiguous input span of 256*R outputs once (coalesced,
 // zeros outside the clip = SciPy's zero padding) and every thread slides over the span
-// accumulating R consecutive outputs, so each staged sample is read from LDS once per thread
-// instead of n_taps/down times from L1.  Taps are wave-uniform per step.  Same products, same
-// increasing-input-index order and no FMA contraction: still bit-exact against SciPy.
+// accumulating R = 4 consecutive outputs.  Per 4 input samples: one 16-byte LDS read of the
+// span, four 16-byte broadcast reads of the tap table hs4[d] = the taps outputs 0..3 apply to
+// sample d (zero outside the filter), and 8 + 8 packed multiplies / adds (two outputs per
+// instruction).  Same products, same increasing-input-index order and no FMA contraction:
+// still bit-exact against SciPy.
 #define AP_RSP_R 4
-AP_DEV int ap_rsp_pad(int a) { return a + (a >> 5); }   // break the R*down lane stride across banks
+struct __attribute__((aligned(16))) ap_rsp_f4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) ap_rsp_f4u { float x, y, z, w; };   // 4-byte aligned 16-byte load
+// two outputs per instruction; the multiply and the add are spelled inside the kernel so that
+// its `fp contract(off)` covers them (hipcc's default would fuse them into one rounding)
+#ifdef AP_PACKED_COMPLEX
+#define AP_RSP_MAC(acc, hx, hy, xv) acc = acc + ap_mk(hx, hy) * ap_mk(xv, xv)
+#else
+#define AP_RSP_MAC(acc, hx, hy, xv) do { acc.x = acc.x + (hx) * (xv); acc.y = acc.y + (hy) * (xv); } while (0)
+#endif
 
+// Q = quad-groups of outputs per thread (outputs o0 + 1024 q + 4 tid + r): one tap read serves Q
+// groups, which moves the loop from LDS-issue bound to VALU bound
+template <int Q>
 __global__ void __launch_bounds__(AP_BLOCK)
 ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps, int n_taps,
                          int n_pre_remove, int64_t n_out, int64_t blocks_per_row, float *out) {
@@ -277,43 +290,76 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
     const int tid = threadIdx.x;
     const int R = AP_RSP_R;
     const int margin = down * (R - 1);
-    const int n_h = n_taps + 2 * margin;                    // taps zero-padded by `margin` each side
-    float *hs = reinterpret_cast<float *>(ap_smem);
-    float *xs = hs + ((n_h + 3) & ~3);
+    const int steps = (n_taps + margin + 3) & ~3;           // d = 0 .. n_taps-1+margin, rounded up to 4
+    ap_rsp_f4 *hs4 = reinterpret_cast<ap_rsp_f4 *>(ap_smem);
+    float *xs = reinterpret_cast<float *>(hs4 + steps);
     const int64_t bid = blockIdx.x;
     const int64_t b = bid / blocks_per_row;
-    const int64_t o0 = (bid - b * blocks_per_row) * (AP_BLOCK * R);
-    const int span = AP_BLOCK * R * down + n_taps - 1;      // input samples this workgroup touches
+    const int64_t o0 = (bid - b * blocks_per_row) * (AP_BLOCK * R * Q);
+    const int span = AP_BLOCK * R * Q * down + steps;       // input samples this workgroup touches (+ tail)
     const int64_t s0 = (o0 + n_pre_remove) * (int64_t)down - (n_taps - 1);   // first of them (may be < 0)
     const float *xb = x + b * L;
-    for (int i = tid; i < n_h; i += AP_BLOCK) {
-        const int j = i - margin;
-        hs[i] = (j >= 0 && j < n_taps) ? taps[j] : 0.0f;
+    for (int i = tid; i < steps * R; i += AP_BLOCK) {
+        // output r sees sample d through tap (n_taps-1) - d + down*r (zero outside the filter)
+        const int d = i >> 2, r = i & 3;
+        const int j = (n_taps - 1) - d + down * r;
+        reinterpret_cast<float *>(hs4)[i] = (j >= 0 && j < n_taps) ? taps[j] : 0.0f;
     }
-    for (int i = tid; i < span; i += AP_BLOCK) {
+    // stage the span 4 samples per thread and step (span is a multiple of 4; LDS side 16-byte
+    // aligned, global side only 4-byte aligned)
+    for (int i = 4 * tid; i < span; i += 4 * AP_BLOCK) {
         const int64_t g = s0 + i;
-        xs[ap_rsp_pad(i)] = (g >= 0 && g < L) ? xb[g] : 0.0f;
+        ap_rsp_f4 v;
+        if (g >= 0 && g + 3 < L) {
+            const ap_rsp_f4u u = *reinterpret_cast<const ap_rsp_f4u *>(xb + g);
+            v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+        } else {
+            v.x = (g >= 0 && g < L) ? xb[g] : 0.0f;
+            v.y = (g + 1 >= 0 && g + 1 < L) ? xb[g + 1] : 0.0f;
+            v.z = (g + 2 >= 0 && g + 2 < L) ? xb[g + 2] : 0.0f;
+            v.w = (g + 3 >= 0 && g + 3 < L) ? xb[g + 3] : 0.0f;
+        }
+        *reinterpret_cast<ap_rsp_f4 *>(xs + i) = v;
     }
     AP_LDS_BARRIER();
-    // thread -> outputs o0 + R*tid + r; its window starts at xs[R*down*tid]
-    float acc[AP_RSP_R];
+    // group q of this thread starts its window at xs[(1024 q + 4 tid) * down] (16-byte aligned)
+    ap_float2 acc01[Q], acc23[Q];
+    const ap_rsp_f4 *xq[Q];
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-    const int xbase = R * down * tid;
-    const int steps = n_taps + margin;                      // d = 0 .. n_taps-1+margin
-    for (int d = 0; d < steps; ++d) {
-        const float xv = xs[ap_rsp_pad(xbase + d)];
+    for (int q = 0; q < Q; ++q) {
+        acc01[q] = ap_mk(0.0f, 0.0f);
+        acc23[q] = ap_mk(0.0f, 0.0f);
+        xq[q] = reinterpret_cast<const ap_rsp_f4 *>(xs + (AP_BLOCK * R * q + R * tid) * down);
+    }
+    for (int d = 0; d < steps; d += 4) {
+        const ap_rsp_f4 h0 = hs4[d], h1 = hs4[d + 1], h2 = hs4[d + 2], h3 = hs4[d + 3];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // output r sees this sample through tap (n_taps-1) - d + down*r (zero outside the filter)
-            const float h = hs[(n_taps - 1) - d + down * r + margin];
-            acc[r] = acc[r] + h * xv;
+        for (int q = 0; q < Q; ++q) {
+            const ap_rsp_f4 xv = xq[q][d >> 2];
+            AP_RSP_MAC(acc01[q], h0.x, h0.y, xv.x);
+            AP_RSP_MAC(acc23[q], h0.z, h0.w, xv.x);
+            AP_RSP_MAC(acc01[q], h1.x, h1.y, xv.y);
+            AP_RSP_MAC(acc23[q], h1.z, h1.w, xv.y);
+            AP_RSP_MAC(acc01[q], h2.x, h2.y, xv.z);
+            AP_RSP_MAC(acc23[q], h2.z, h2.w, xv.z);
+            AP_RSP_MAC(acc01[q], h3.x, h3.y, xv.w);
+            AP_RSP_MAC(acc23[q], h3.z, h3.w, xv.w);
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int64_t o = o0 + (int64_t)R * tid + r;
-        if (o < n_out) out[b * n_out + o] = acc[r];
+    for (int q = 0; q < Q; ++q) {
+        const int64_t o = o0 + (int64_t)(AP_BLOCK * R) * q + (int64_t)R * tid;
+        float *dst = out + b * n_out + o;
+        if (o + 3 < n_out && ((b * n_out + o) & 3) == 0) {
+            ap_rsp_f4 v;
+            v.x = acc01[q].x; v.y = acc01[q].y; v.z = acc23[q].x; v.w = acc23[q].y;
+            *reinterpret_cast<ap_rsp_f4 *>(dst) = v;
+        } else {
+            if (o < n_out) dst[0] = acc01[q].x;
+            if (o + 1 < n_out) dst[1] = acc01[q].y;
+            if (o + 2 < n_out) dst[2] = acc23[q].x;
+            if (o + 3 < n_out) dst[3] = acc23[q].y;
+        }
     }
 }
 

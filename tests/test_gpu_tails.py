@@ -48,7 +48,7 @@ def test_resample_poly_api(batch_signals):
         ap.resample_poly(y, 0, 1)
 
 
-@pytest.mark.parametrize("down,L", [(2, 50001), (3, 48000), (4, 22050), (5, 9999), (7, 3000), (3, 50)])
+@pytest.mark.parametrize("down,L", [(2, 50001), (3, 48000), (4, 22050), (5, 9999), (7, 3000), (8, 70001), (3, 50)])
 def test_resample_poly_decimator_bit_exact(down, L):
     """LDS-tiled register-blocked decimator (up == 1) against SciPy, bit for bit."""
     import scipy.signal
