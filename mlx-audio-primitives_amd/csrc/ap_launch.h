@@ -329,6 +329,7 @@ static inline int ap_prepare_irfft_wave(ApIrfftWaveParams &W, const ApIrfftParam
     W.off_ob = off; off += ap_align16(2 * APS_OB_ROWS * APS_OB_ROW * (int)sizeof(ap_float2));
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;
+    if (W.T > (1 << 20)) return 1;                        // 32-bit row offsets (1024 T complex)
     int64_t g = W.n_groups < 256 ? W.n_groups : 256;
     *grid = (int)g;
     return AP_OK;

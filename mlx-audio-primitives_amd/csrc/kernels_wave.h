@@ -580,25 +580,43 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
 
     const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
     const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    // thread (sq = tid / 8, sf = tid % 8) fetches frame sf of rows sq, 64 + sq, 128 + sq, 192 + sq of
+    // every chunk (bins 64 r + sq and 1024 - 64 r - sq, r = 2c, 2c + 1) -- the whole group one
+    // iteration ahead, into registers, so that HBM latency is paid under the previous transform
+    // and not once per chunk
+    const int sq = tid >> 3, sf = tid & 7;
+    const int Ti = (int)P.T;
+    ap_float2 pre[4][4], pre_mid = ap_mk(0.0f, 0.0f);
+    auto load_group = [&](int64_t group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
+        const bool live = t0 + sf < P.T;
+        const ap_float2 *sb = P.S + b * (int64_t)F * P.T + t0 + sf;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * c + (i >> 1);
+                const int bin = (i & 1) ? APW_NC - 64 * r - sq : 64 * r + sq;
+                pre[c][i] = live ? sb[bin * Ti] : ap_mk(0.0f, 0.0f);
+            }
+        if (tid < APS_WAVES) pre_mid = live ? sb[(APW_NC / 2) * Ti] : ap_mk(0.0f, 0.0f);
+    };
+    if (g_lo < g_hi) load_group(g_lo);
     for (int64_t group = g_lo; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;
         const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
         const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
-        const ap_float2 *sb = P.S + b * (int64_t)F * P.T + t0;
 
-        // ---- transposed load: every wave collects its frame's bins in registers -----------
+        // ---- transpose through LDS: every wave collects its frame's bins in registers -------
         ap_float2 xk[8], xm[8], xh = ap_mk(0.0f, 0.0f);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             ap_float2 *buf = IB + (c & 1) * (APS_OB_ROWS * APS_OB_ROW);
-            const int rows = c == 3 ? 257 : 256;
-            for (int e = tid; e < rows * APS_WAVES; e += 64 * APS_WAVES) {
-                const int row = e >> 3, f = e & 7;
-                const int rr = row >> 7, q = row & 127;
-                const int r = 2 * c + rr;
-                const int bin = row == 256 ? APW_NC / 2 : (q < 64 ? 64 * r + q : APW_NC - 64 * r - (q - 64));
-                buf[row * APS_OB_ROW + f] = f < Gt ? sb[(int64_t)bin * P.T + f] : ap_mk(0.0f, 0.0f);
-            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                buf[((i >> 1) * 128 + (i & 1) * 64 + sq) * APS_OB_ROW + sf] = pre[c][i];
+            if (c == 3 && tid < APS_WAVES) buf[256 * APS_OB_ROW + sf] = pre_mid;
             AP_LDS_BARRIER();
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -607,6 +625,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
             }
             if (c == 3) xh = buf[256 * APS_OB_ROW + wave];
         }
+        AP_SCHED_FENCE();
+        if (group + 1 < g_hi) load_group(group + 1);
+        AP_SCHED_FENCE();
         // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[1024-k]) / 2 of the packed inverse -----
         //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = (W^-k / 2) d
         //   conj Z[k] / 2 = conj(a/2 + i o),  conj Z[1024-k] / 2 = a/2 - i o
