@@ -258,7 +258,9 @@ int ap_reduce_max_f32(const float *x /*dev*/, int64_t n, uint32_t *key_dev, void
 
 /* _to_db (convert.py:14-60): out = coef*log10(max(S,amin)/max(ref,amin)), then if
  * top_db >= 0: out = max(out, GLOBAL max(out) - top_db).  ref = *ref_key_dev (a key from
- * ap_reduce_max_f32) when ref_key_dev != NULL, else ref_value.  ws_dev: 4-byte scratch. */
+ * ap_reduce_max_f32) when ref_key_dev != NULL, else ref_value.  ws_dev: 4-byte scratch.
+ * The conversion is monotone, so the clip floor is dB(max(S)) - top_db: one read-only max
+ * reduction of S, then a single read+write pass. */
 int ap_to_db_f32(const float *S /*dev*/, int64_t n, float coef, float amin, float ref_value,
                  const uint32_t *ref_key_dev, float top_db, float *out /*dev*/,
                  uint32_t *ws_dev, void *stream);
@@ -274,6 +276,15 @@ int ap_from_db_f32(const float *x /*dev*/, int64_t n, float ref, float div, floa
 int ap_dct_f32(const float *x /*dev*/, const float *C /*dev (n_out,n_in)*/,
                const float *row_scale /*dev or NULL*/, int64_t outer, int n_in, int64_t inner,
                int n_out, float *out /*dev*/, void *stream);
+
+/* mfcc tail (mfcc.py:253-287): power_to_db (+ top_db clip against the global maximum) fused into
+ * the DCT's loads: out[o,k,i] = row_scale[k] * sum_m C[k,m] * dB(S[o,m,i]).  The dB array is
+ * never materialised.  Arguments as in ap_to_db_f32 and ap_dct_f32; n_in * 64 (n_out <= 16) or
+ * n_in * 128 bytes must fit 64 KiB of LDS (AP_ERR_UNSUPPORTED otherwise: use the two calls). */
+int ap_db_dct_f32(const float *S /*dev*/, const float *C /*dev (n_out,n_in)*/,
+                  const float *row_scale /*dev or NULL*/, int64_t outer, int n_in, int64_t inner,
+                  int n_out, float coef, float amin, float ref_value, const uint32_t *ref_key_dev,
+                  float top_db, uint32_t *ws_dev, float *out /*dev*/, void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "ap_magnitude_f32", "ap_phase_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
-    "ap_from_db_f32", "ap_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
+    "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
 ]
 
@@ -90,6 +90,7 @@ def _declare(lib) -> None:
         "ap_to_db_f32": [P, L, F, F, F, P, F, P, P, P],
         "ap_from_db_f32": [P, L, F, F, P, P],
         "ap_dct_f32": [P, P, P, L, I, L, I, P, P],
+        "ap_db_dct_f32": [P, P, P, L, I, L, I, F, F, F, P, F, P, P, P],
         "ap_cfft_split_host": [L, P, P],
         "ap_pcg64_uniform_f32": [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                  ctypes.c_double, ctypes.c_double, L, P, P],

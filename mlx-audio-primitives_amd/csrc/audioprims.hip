@@ -318,18 +318,15 @@ int ap_to_db_f32(const float *S, int64_t n, float coef, float amin, float ref_va
     const bool clip = top_db >= 0.0f;
     if (clip && !ws_dev) AP_FAIL(AP_ERR_INVALID, "to_db: top_db needs a scratch word");
     if (clip) {
-        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)ws_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
-        if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+        int rc = ap_reduce_max_f32(S, n, ws_dev, stream);      // max(out) = dB(max(S)): see kernels_pointwise.h
+        if (rc != AP_OK) return rc;
     }
+    ApDbParams D;
+    D.coef = coef; D.amin = amin; D.ref_value = ref_value; D.top_db = clip ? top_db : -1.0f;
+    D.ref_key = ref_key_dev; D.smax_key = ws_dev;
     const int grid = ap_grid_1d(n, AP_BLOCK, kApStreamGrid);
-    hipLaunchKernelGGL(ap_to_db_kernel, dim3(grid), dim3(AP_BLOCK), AP_BLOCK * sizeof(float),
-                       (hipStream_t)stream, S, n, coef, amin, ref_value, ref_key_dev, out,
-                       clip ? ws_dev : (uint32_t *)nullptr);
-    int rc = ap_check_launch("ap_to_db_f32");
-    if (rc != AP_OK || !clip) return rc;
-    hipLaunchKernelGGL(ap_clip_db_kernel, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, out, n,
-                       top_db, ws_dev);
-    return ap_check_launch("ap_to_db_f32(clip)");
+    hipLaunchKernelGGL(ap_to_db_kernel, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, S, n, D, out);
+    return ap_check_launch("ap_to_db_f32");
 }
 
 int ap_from_db_f32(const float *x, int64_t n, float ref, float div, float *out, void *stream) {
@@ -340,19 +337,72 @@ int ap_from_db_f32(const float *x, int64_t n, float ref, float div, float *out, 
     return ap_check_launch("ap_from_db_f32");
 }
 
+}  // extern "C"
+
+template <int DB>
+static int ap_launch_dct(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
+                         int64_t inner, int n_out, const ApDbParams &D, float *out, void *stream,
+                         bool *handled) {
+    *handled = false;
+    const int KT = n_out <= 16 ? 16 : 32;
+    const int lds = n_in * KT * (int)sizeof(float);
+    if (lds > 64 * 1024) return AP_OK;
+    *handled = true;
+    const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
+    int rc;
+    if (KT == 16) {
+        rc = ap_allow_lds(ap_dct_kernel<16, DB>, lds);
+        if (rc != AP_OK) return rc;
+        hipLaunchKernelGGL((ap_dct_kernel<16, DB>), dim3(grid), dim3(AP_BLOCK), lds, (hipStream_t)stream, x, C,
+                           row_scale, outer, n_in, inner, n_out, D, out);
+    } else {
+        rc = ap_allow_lds(ap_dct_kernel<32, DB>, lds);
+        if (rc != AP_OK) return rc;
+        hipLaunchKernelGGL((ap_dct_kernel<32, DB>), dim3(grid), dim3(AP_BLOCK), lds, (hipStream_t)stream, x, C,
+                           row_scale, outer, n_in, inner, n_out, D, out);
+    }
+    return ap_check_launch("ap_dct_f32");
+}
+
+extern "C" {
 int ap_dct_f32(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
                int64_t inner, int n_out, float *out, void *stream) {
     if (!x || !C || !out) AP_FAIL(AP_ERR_INVALID, "dct: NULL buffer");
     if (n_in <= 0 || n_out <= 0) AP_FAIL(AP_ERR_INVALID, "dct: sizes must be positive");
     if (outer <= 0 || inner <= 0) return AP_OK;
+    ApDbParams D = {};
+    bool handled = false;
+    int rc = ap_launch_dct<0>(x, C, row_scale, outer, n_in, inner, n_out, D, out, stream, &handled);
+    if (rc != AP_OK || handled) return rc;
     const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
     if (n_out <= 16)
-        hipLaunchKernelGGL(ap_dct_kernel<16>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
+        hipLaunchKernelGGL(ap_dct_generic_kernel<16>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
                            row_scale, outer, n_in, inner, n_out, out);
     else
-        hipLaunchKernelGGL(ap_dct_kernel<32>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
+        hipLaunchKernelGGL(ap_dct_generic_kernel<32>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, x, C,
                            row_scale, outer, n_in, inner, n_out, out);
     return ap_check_launch("ap_dct_f32");
+}
+
+int ap_db_dct_f32(const float *S, const float *C, const float *row_scale, int64_t outer, int n_in,
+                  int64_t inner, int n_out, float coef, float amin, float ref_value,
+                  const uint32_t *ref_key_dev, float top_db, uint32_t *ws_dev, float *out, void *stream) {
+    if (!S || !C || !out) AP_FAIL(AP_ERR_INVALID, "db_dct: NULL buffer");
+    if (n_in <= 0 || n_out <= 0) AP_FAIL(AP_ERR_INVALID, "db_dct: sizes must be positive");
+    if (outer <= 0 || inner <= 0) return AP_OK;
+    const bool clip = top_db >= 0.0f;
+    if (clip && !ws_dev) AP_FAIL(AP_ERR_INVALID, "db_dct: top_db needs a scratch word");
+    if (n_in * (n_out <= 16 ? 16 : 32) * (int)sizeof(float) > 64 * 1024)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "db_dct: n_in=%d too long for the fused kernel (use ap_to_db_f32 + ap_dct_f32)", n_in);
+    if (clip) {
+        int rc = ap_reduce_max_f32(S, outer * n_in * inner, ws_dev, stream);
+        if (rc != AP_OK) return rc;
+    }
+    ApDbParams D;
+    D.coef = coef; D.amin = amin; D.ref_value = ref_value; D.top_db = clip ? top_db : -1.0f;
+    D.ref_key = ref_key_dev; D.smax_key = ws_dev;
+    bool handled = false;
+    return ap_launch_dct<1>(S, C, row_scale, outer, n_in, inner, n_out, D, out, stream, &handled);
 }
 
 static int ap_launch_cfft_leg(const ApCfftParams &C, int64_t B, void *stream) {

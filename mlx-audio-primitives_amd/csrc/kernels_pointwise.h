@@ -74,38 +74,32 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_reduce_max_kernel(const float *x,
 
 // pass 1 of _to_db (convert.py:42-54): out = coef * log10(max(S, amin) / max(ref, amin));
 // ref is *ref_key (max key of a previous reduction) when ref_key != NULL, else ref_value.
-// Also reduces max(out) into *max_key for the top_db clip.
-__global__ void __launch_bounds__(AP_BLOCK)
-ap_to_db_kernel(const float *S, int64_t n, float coef, float amin, float ref_value,
-                const unsigned *ref_key, float *out, unsigned *max_key) {
-    float *red = reinterpret_cast<float *>(ap_smem);
-    const float ref = fmaxf(ref_key ? ap_fkey_inv(*ref_key) : ref_value, amin);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float m = -INFINITY;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const float v = coef * log10f(fmaxf(S[e], amin) / ref);
-        out[e] = v;
-        m = fmaxf(m, v);
-    }
-    if (max_key) {
-        red[threadIdx.x] = m;
-        __syncthreads();
-        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) ap_atomic_max_u32(max_key, ap_fkey(red[0]));
-    }
+// top_db clip (convert.py:56-58: out = max(out, GLOBAL max(out) - top_db)): the conversion is
+// monotone, so max(out) = dB(max(S)) and the floor is known from a read-only max reduction of S
+// (*smax_key) before this single read+write pass.
+struct ApDbParams {
+    float coef, amin, ref_value, top_db;     // top_db < 0: no clip
+    const unsigned *ref_key, *smax_key;
+};
+AP_DEV float ap_db_ref(const ApDbParams &D) {
+    return fmaxf(D.ref_key ? ap_fkey_inv(*D.ref_key) : D.ref_value, D.amin);
+}
+AP_DEV float ap_db_value(const ApDbParams &D, float ref, float s) {
+    return D.coef * log10f(fmaxf(s, D.amin) / ref);
+}
+AP_DEV float ap_db_floor(const ApDbParams &D, float ref) {
+    return D.top_db >= 0.0f ? ap_db_value(D, ref, ap_fkey_inv(*D.smax_key)) - D.top_db : -INFINITY;
 }
 
-// pass 2 (convert.py:56-58): out = max(out, max(out) - top_db), GLOBAL max over the whole array
 __global__ void __launch_bounds__(AP_BLOCK)
-ap_clip_db_kernel(float *out, int64_t n, float top_db, const unsigned *max_key) {
-    const float floor_v = ap_fkey_inv(*max_key) - top_db;
+ap_to_db_kernel(const float *S, int64_t n, ApDbParams D, float *out) {
+    const float ref = ap_db_ref(D);
+    const float floor_v = ap_db_floor(D, ref);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
-        out[e] = fmaxf(out[e], floor_v);
+        out[e] = fmaxf(ap_db_value(D, ref, S[e]), floor_v);
 }
+
 
 // db_to_power / db_to_amplitude (convert.py:100-129, 169-198): ref * 10^(x / div)
 __global__ void __launch_bounds__(AP_BLOCK)
@@ -116,12 +110,61 @@ ap_from_db_kernel(const float *x, int64_t n, float ref, float div, float *out) {
 }
 
 // DCT-II (any small dense basis) along the middle axis of x viewed as (outer, n_in, inner):
-//   out[o, k, i] = row_scale[k] * sum_m C[k, m] * x[o, m, i]        (mfcc.py:135, :277-282)
-// One thread per (o, i); C[k, m] is wave-uniform (scalar loads); KT outputs per pass.
-template <int KT>
+//   out[o, k, i] = row_scale[k] * sum_m C[k, m] * x'[o, m, i]        (mfcc.py:135, :277-282)
+// x' = x, or with DB = 1 the dB conversion (+ top_db clip) of x applied on the fly, so mfcc
+// (mfcc.py:253-262) reads the mel power once and never writes the dB array.
+// One thread per (o, i), all KT outputs of a chunk in registers; the basis sits transposed in
+// LDS ([m][KT], 16-byte broadcast reads) and the loads of 8 input rows are issued together.
+template <int KT, int DB>
 __global__ void __launch_bounds__(AP_BLOCK)
 ap_dct_kernel(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
-              int64_t inner, int n_out, float *out) {
+              int64_t inner, int n_out, ApDbParams D, float *out) {
+    float *Ct = reinterpret_cast<float *>(ap_smem);                 // [n_in][KT]
+    const int64_t total = outer * inner;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float ref = 1.0f, floor_v = 0.0f;
+    if (DB) { ref = ap_db_ref(D); floor_v = ap_db_floor(D, ref); }
+    for (int k0 = 0; k0 < n_out; k0 += KT) {
+        AP_LDS_BARRIER();
+        for (int i = threadIdx.x; i < n_in * KT; i += AP_BLOCK) {
+            const int m = i / KT, k = i - m * KT;
+            Ct[i] = k0 + k < n_out ? C[(int64_t)(k0 + k) * n_in + m] : 0.0f;
+        }
+        AP_LDS_BARRIER();
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+            const int64_t o = e / inner, i = e - o * inner;
+            const float *xp = x + o * n_in * inner + i;
+            float *op = out + o * n_out * inner + i;
+            float acc[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k] = 0.0f;
+            for (int m0 = 0; m0 < n_in; m0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = m0 + j < n_in ? xp[(int64_t)(m0 + j) * inner] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (m0 + j < n_in) {
+                        const float vv = DB ? fmaxf(ap_db_value(D, ref, v[j]), floor_v) : v[j];
+                        const float *c = Ct + (m0 + j) * KT;
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) acc[k] = fmaf(c[k], vv, acc[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+                if (k0 + k < n_out)
+                    op[(int64_t)(k0 + k) * inner] = row_scale ? acc[k] * row_scale[k0 + k] : acc[k];
+        }
+    }
+}
+
+// any n_in (basis read through the scalar cache): fallback when the transposed basis does not fit LDS
+template <int KT>
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_dct_generic_kernel(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
+                      int64_t inner, int n_out, float *out) {
     const int64_t total = outer * inner;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {

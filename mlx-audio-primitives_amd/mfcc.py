@@ -74,12 +74,34 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
     batched = S.ndim == 3
     if not batched:
         S = S[None, :]
-    # a provided S is taken to be log-power already (mfcc.py:253-258)
-    S_db = S if provided else power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0)
     lift = None
     if lifter > 0:
         nn = np.arange(n_mfcc)
         lift = torch.from_numpy(
-            (1 + (lifter / 2.0) * np.sin(np.pi * (nn + 1) / lifter)).astype(np.float32)).to(S_db.device)
-    M = dct(S_db, type=dct_type, n=n_mfcc, axis=1, norm=norm, _row_scale=lift)
+            (1 + (lifter / 2.0) * np.sin(np.pi * (nn + 1) / lifter)).astype(np.float32)).to(S.device)
+    if provided:
+        # a provided S is taken to be log-power already (mfcc.py:253-258)
+        M = dct(S, type=dct_type, n=n_mfcc, axis=1, norm=norm, _row_scale=lift)
+    else:
+        M = _db_dct(S, dct_type, n_mfcc, norm, lift)
     return M if batched else M[0]
+
+
+def _db_dct(S: torch.Tensor, dct_type: int, n_mfcc: int, norm, lift) -> torch.Tensor:
+    """power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0) followed by the DCT along axis 1
+    (mfcc.py:259-287) in one pass over S: ap_db_dct_f32 converts on load, so the dB array is
+    never written.  Falls back to the two calls when the basis does not fit LDS."""
+    if dct_type != 2:
+        raise ValueError(f"Only DCT type 2 is supported, got {dct_type}")
+    B, n_in, inner = S.shape
+    if n_in * (16 if n_mfcc <= 16 else 32) * 4 > 64 * 1024:
+        return dct(power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0), type=dct_type, n=n_mfcc, axis=1,
+                   norm=norm, _row_scale=lift)
+    C = _dct_matrix(int(n_mfcc), int(n_in), norm, S.device)
+    out = torch.empty((B, int(n_mfcc), inner), dtype=torch.float32, device=S.device)
+    if out.numel():
+        ws = torch.empty(1, dtype=torch.int32, device=S.device)
+        _x.check(_x.lib().ap_db_dct_f32(_x.ptr(S), _x.ptr(C), None if lift is None else _x.ptr(lift),
+                                        B, int(n_in), inner, int(n_mfcc), 10.0, 1e-10, 1.0, None, 80.0,
+                                        ws.data_ptr(), _x.ptr(out), _x.stream_ptr(S.device)))
+    return out

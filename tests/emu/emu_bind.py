@@ -209,13 +209,18 @@ def to_db(S, coef=10.0, amin=1e-10, ref=1.0, ref_is_max=False, top_db=80.0):
     return out
 
 
-def dct(x, C, outer, n_in, inner, row_scale=None):
+def dct(x, C, outer, n_in, inner, row_scale=None, db=None):
+    """db = (coef, amin, ref_value, top_db or None): fused power_to_db + DCT (ap_db_dct_f32)."""
     x = np.ascontiguousarray(x, np.float32)
     C = np.ascontiguousarray(C, np.float32)
     n_out = C.shape[0]
     out = np.zeros(outer * n_out * inner, np.float32)
     rs = _p(np.ascontiguousarray(row_scale, np.float32)) if row_scale is not None else None
-    _check(lib().emu_dct_f32(_p(x), _p(C), rs, _i64(outer), n_in, _i64(inner), n_out, _p(out)))
+    f = ctypes.c_float
+    coef, amin, ref, top = db if db is not None else (0.0, 0.0, 0.0, None)
+    _check(lib().emu_dct_f32(_p(x), _p(C), rs, _i64(outer), n_in, _i64(inner), n_out,
+                             int(db is not None), f(coef), f(amin), f(ref),
+                             f(-1.0 if top is None else top), _p(out)))
     return out
 
 

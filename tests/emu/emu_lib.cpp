@@ -179,21 +179,38 @@ int emu_to_db_f32(const float *S, int64_t n, float coef, float amin, float ref_v
     const int grid = ap_grid_1d(n, AP_BLOCK, kApStreamGrid);
     if (ref_is_max) emu_launch(grid, AP_BLOCK, [&] { ap_reduce_max_kernel(S, n, &keys[1]); });
     const bool clip = top_db >= 0.0f;
-    emu_launch(grid, AP_BLOCK, [&] {
-        ap_to_db_kernel(S, n, coef, amin, ref_value, ref_is_max ? &keys[1] : nullptr, out,
-                        clip ? &keys[0] : nullptr);
-    });
-    if (clip) emu_launch(grid, AP_BLOCK, [&] { ap_clip_db_kernel(out, n, top_db, &keys[0]); });
+    if (clip) emu_launch(grid, AP_BLOCK, [&] { ap_reduce_max_kernel(S, n, &keys[0]); });
+    ApDbParams D;
+    D.coef = coef; D.amin = amin; D.ref_value = ref_value; D.top_db = clip ? top_db : -1.0f;
+    D.ref_key = ref_is_max ? &keys[1] : nullptr; D.smax_key = &keys[0];
+    emu_launch(grid, AP_BLOCK, [&] { ap_to_db_kernel(S, n, D, out); });
     return AP_OK;
 }
 
+// db = 1: fused power_to_db (ref_value, amin, top_db) + DCT, like ap_db_dct_f32
 int emu_dct_f32(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
-                int64_t inner, int n_out, float *out) {
+                int64_t inner, int n_out, int db, float coef, float amin, float ref_value, float top_db,
+                float *out) {
     const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
-    if (n_out <= 16)
-        emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<16>(x, C, row_scale, outer, n_in, inner, n_out, out); });
-    else
-        emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32>(x, C, row_scale, outer, n_in, inner, n_out, out); });
+    unsigned key = 0x007FFFFFu;
+    ApDbParams D = {};
+    if (db) {
+        const bool clip = top_db >= 0.0f;
+        if (clip) emu_launch(grid, AP_BLOCK, [&] { ap_reduce_max_kernel(x, outer * n_in * inner, &key); });
+        D.coef = coef; D.amin = amin; D.ref_value = ref_value; D.top_db = clip ? top_db : -1.0f;
+        D.ref_key = nullptr; D.smax_key = &key;
+    }
+    const int KT = n_out <= 16 ? 16 : 32;
+    if (n_in * KT * 4 > 64 * 1024) {
+        if (db) return AP_ERR_UNSUPPORTED;
+        if (KT == 16) emu_launch(grid, AP_BLOCK, [&] { ap_dct_generic_kernel<16>(x, C, row_scale, outer, n_in, inner, n_out, out); });
+        else emu_launch(grid, AP_BLOCK, [&] { ap_dct_generic_kernel<32>(x, C, row_scale, outer, n_in, inner, n_out, out); });
+        return AP_OK;
+    }
+    if (KT == 16 && db) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<16, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
+    else if (KT == 16) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<16, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
+    else if (db) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
+    else emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
     return AP_OK;
 }
 

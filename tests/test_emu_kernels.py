@@ -171,6 +171,13 @@ def test_emu_db_dct_and_gl_projection():
     np.testing.assert_allclose(got, ao.dct(x, n=13, axis=1), rtol=1e-4, atol=1e-4)
     got = eb.dct(x, ao.dct_matrix(20, 50), 120, 50, 1).reshape(3, 40, 20)
     np.testing.assert_allclose(got, ao.dct(x, n=20, axis=-1), rtol=1e-4, atol=1e-4)
+    # fused power_to_db (+ top_db clip against the global maximum) + DCT = the mfcc tail
+    for top in (80.0, 30.0, None):
+        got = eb.dct(S, C, 3, 40, 50, db=(10.0, 1e-10, 1.0, top)).reshape(3, 13, 50)
+        want = ao.dct(ao.power_to_db(S, top_db=top), n=13, axis=1)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
+    got = eb.dct(x, ao.dct_matrix(24, 40), 3, 40, 50).reshape(3, 24, 50)       # 32-wide chunks
+    np.testing.assert_allclose(got, ao.dct(x, n=24, axis=1), rtol=1e-4, atol=1e-4)
     # Griffin-Lim projection: init and one momentum step, with a shorter R (zero-padded frames)
     Sm = np.abs(rng.standard_normal((2, 9, 7))).astype(np.float32)
     ang = rng.uniform(-np.pi, np.pi, Sm.shape).astype(np.float32)
