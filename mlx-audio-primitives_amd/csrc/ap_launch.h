@@ -229,6 +229,19 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
 }
 
 // compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
+// LDS geometry of the compile-time engine (shared with kernels_ct.h).  A frame's complex slot
+// idx lives at idx + (idx >> sh), sh = log2(first radix): the Stockham pass that writes with
+// stride R0 then hits R0 + 1 apart (conflict-free ds_write_b64); the frame stride FS and the
+// |X|^p plane stride PS are = 4 (mod 32) so that the 8 frames x 4 bins a half-wave touches in
+// the split / power / contraction steps fall into different banks.
+static inline int ap_ct_pad_shift(int n_fft) { return n_fft == 400 ? 3 : 4; }
+static inline int ap_ct_round4mod32(int v) { return ((v + 27) / 32) * 32 + 4; }
+static inline int ap_ct_fs(int n_fft) {
+    const int nc = n_fft / 2;
+    return ap_ct_round4mod32(nc + (nc >> ap_ct_pad_shift(n_fft)) + 1);
+}
+static inline int ap_ct_ps(int n_fft) { return ap_ct_round4mod32(n_fft / 2 + 1 + 3); }
+
 static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels, int *G, int *lds_bytes) {
     int g;
     if (n_fft == 400) g = 8;
@@ -237,7 +250,7 @@ static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels,
     else return false;
     const int nc = n_fft / 2;
     *G = g;
-    int bytes = (2 * g * (nc + 1) + n_fft + nc) * (int)sizeof(ap_float2);
+    int bytes = (2 * g * ap_ct_fs(n_fft) + n_fft + nc) * (int)sizeof(ap_float2);
     // mel plan tables + partial sums [n_parts][G] + rowstart
     bytes += n_quads * 16 + n_parts * 16 + n_parts * g * 4 + (n_parts > 0 ? (n_mels + 1) * 4 : 0) + 64;
     *lds_bytes = bytes;

@@ -8,10 +8,13 @@
 #include "kernels_generic.h"
 #include "kernels_wave.h"     // ApClip / ap_clip_load / ap_float4
 
-template <int R, int NC, int NS, int G>
+// padded slot of complex index idx inside a frame (ap_launch.h: ap_ct_pad_shift)
+template <int SH>
+AP_DEV constexpr int ap_ct_pad(int idx) { return idx + (idx >> SH); }
+
+template <int R, int NC, int NS, int G, int SH, int FS>
 AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_float2 *twl, int tid) {
     constexpr int PER = NC / R;
-    constexpr int FS = NC + 1;
     constexpr int TMUL = (NC / (NS * R)) * 2;          // W_{NS*R}^1 in the W_n table (n = 2 NC)
     for (int item = tid; item < G * PER; item += AP_BLOCK) {
         const int g = item / PER;
@@ -21,7 +24,7 @@ AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_fl
         const int k = j % NS;
         ap_float2 v[R];
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[i] = src[j + i * PER];
+        for (int i = 0; i < R; ++i) v[i] = src[ap_ct_pad<SH>(j + i * PER)];
         if (NS > 1) {
             const int tk = TMUL * k;
 #pragma unroll
@@ -30,16 +33,29 @@ AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_fl
         ApButterfly<R>::run(v);
         const int j0 = (j / NS) * NS * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) dst[j0 + q * NS] = v[q];
+        for (int q = 0; q < R; ++q) dst[ap_ct_pad<SH>(j0 + q * NS)] = v[q];
     }
+}
+
+// ap_rfft_split (fft_lds.h) on a padded frame
+template <int SH>
+AP_DEV ap_float2 ap_rfft_split_ct(const ap_float2 *Z, int nc, int k, const ap_float2 *tw) {
+    const ap_float2 zk = Z[ap_ct_pad<SH>(k == nc ? 0 : k)];
+    const ap_float2 zm = Z[ap_ct_pad<SH>(k == 0 ? 0 : nc - k)];
+    const ap_float2 a = ap_add_conj(zk, zm), d = ap_sub_conj(zk, zm);
+    const ap_float2 w = tw[k];   // (cos, sin)(2 pi k / n)
+    // X[k] = a/2 - (i/2) W^k d
+    const ap_float2 u = ap_mul_fw(d, ap_scale(w, 0.5f));
+    return ap_fma_add_mi(a, ap_mk(0.5f, 0.5f), u);
 }
 
 // EPI 0: complex (B,F,T); EPI 1: mel (B,M,T).  R2 = 1: two passes only.
 template <int EPI, int NC, int R0, int R1, int R2, int G, int PADGEN>
 __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
-    constexpr int FS = NC + 1;
     constexpr int N = 2 * NC;
     constexpr int F = NC + 1;
+    constexpr int SH = N == 400 ? 3 : 4;                               // = ap_ct_pad_shift(N)
+    constexpr int FS = ((NC + (NC >> SH) + 1 + 27) / 32) * 32 + 4;     // = ap_ct_fs(N)
     ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
     ap_float2 *bufB = bufA + G * FS;
     ap_float2 *twl = bufB + G * FS;                    // [N] (cos, sin)(2 pi j / N)
@@ -99,7 +115,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                 const int g = item / NC;
                 const int c = item - g * NC;
                 const ap_float2 w = winl[c];
-                bufA[g * FS + c] = ap_mk(w.x * raw[i].x, w.y * raw[i].y);
+                bufA[g * FS + ap_ct_pad<SH>(c)] = ap_mul2(w, raw[i]);
             }
         }
 #ifndef AP_HOST_EMU
@@ -110,14 +126,14 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
         __builtin_amdgcn_sched_barrier(0);
 #endif
         AP_LDS_BARRIER();
-        ap_stockham_pass_ct<R0, NC, 1, G>(bufA, bufB, twl, tid);
+        ap_stockham_pass_ct<R0, NC, 1, G, SH, FS>(bufA, bufB, twl, tid);
         AP_LDS_BARRIER();
-        ap_stockham_pass_ct<R1, NC, R0, G>(bufB, bufA, twl, tid);
+        ap_stockham_pass_ct<R1, NC, R0, G, SH, FS>(bufB, bufA, twl, tid);
         AP_LDS_BARRIER();
         ap_float2 *Z = bufA;
         ap_float2 *other = bufB;
         if (R2 > 1) {
-            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G>(bufA, bufB, twl, tid);
+            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G, SH, FS>(bufA, bufB, twl, tid);
             AP_LDS_BARRIER();
             Z = bufB;
             other = bufA;
@@ -127,16 +143,17 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             for (int item = tid; item < F * G; item += AP_BLOCK) {
                 const int k = item / G;
                 const int g = item - k * G;
-                if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split(Z + g * FS, NC, k, twl);
+                if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split_ct<SH>(Z + g * FS, NC, k, twl);
             }
             AP_LDS_BARRIER();
         } else {
             float *Pw = reinterpret_cast<float *>(other);
-            constexpr int PS = (2 * FS) & ~3;                  // 16-byte aligned planes, >= F + 3
+            constexpr int PS = ((F + 3 + 27) / 32) * 32 + 4;   // = ap_ct_ps(N): 16-byte aligned planes, >= F + 3
+            static_assert(PS <= 2 * FS, "power planes alias the idle exchange buffer");
             for (int item = tid; item < F * G; item += AP_BLOCK) {
                 const int k = item / G;
                 const int g = item - k * G;
-                const ap_float2 X = ap_rfft_split(Z + g * FS, NC, k, twl);
+                const ap_float2 X = ap_rfft_split_ct<SH>(Z + g * FS, NC, k, twl);
                 Pw[g * PS + k] = ap_pow_mag(X.x, X.y, P.power);
             }
             if (P.n_parts > 0) {
