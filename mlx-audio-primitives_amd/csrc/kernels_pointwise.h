@@ -212,6 +212,23 @@ AP_DEV ap_u128 ap_pcg64_advance(ap_u128 state, ap_u128 inc, unsigned long long d
     return acc_mult * state + acc_plus;
 }
 
+// the affine map of `delta` LCG steps: state_{k+delta} = A state_k + C
+AP_DEV void ap_pcg64_affine(ap_u128 inc, unsigned long long delta, ap_u128 &A, ap_u128 &C) {
+    const ap_u128 MULT = ((ap_u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+    ap_u128 cur_mult = MULT, cur_plus = inc;
+    A = 1;
+    C = 0;
+    while (delta > 0) {
+        if (delta & 1) {
+            A *= cur_mult;
+            C = C * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+}
+
 __global__ void __launch_bounds__(AP_BLOCK)
 ap_pcg64_uniform_kernel(unsigned long long st_hi, unsigned long long st_lo, unsigned long long inc_hi,
                         unsigned long long inc_lo, double low, double range, int64_t n, float *out) {
@@ -221,8 +238,14 @@ ap_pcg64_uniform_kernel(unsigned long long st_hi, unsigned long long st_lo, unsi
     const ap_u128 state0 = ((ap_u128)st_hi << 64) | st_lo;
     const ap_u128 inc = ((ap_u128)inc_hi << 64) | inc_lo;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        const ap_u128 s = ap_pcg64_advance(state0, inc, (unsigned long long)e + 1ULL);
+    const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e0 >= n) return;
+    // one O(log) jump to the thread's first element, then the affine map of `stride` LCG steps
+    // (s -> A s + C, built once) from element to element: one 128-bit multiply-add per output
+    ap_u128 s = ap_pcg64_advance(state0, inc, (unsigned long long)e0 + 1ULL);
+    ap_u128 A, C;
+    ap_pcg64_affine(inc, (unsigned long long)stride, A, C);
+    for (int64_t e = e0; e < n; e += stride, s = A * s + C) {
         const unsigned long long hi = (unsigned long long)(s >> 64), lo = (unsigned long long)s;
         const unsigned long long x = hi ^ lo;
         const unsigned rot = (unsigned)(hi >> 58);

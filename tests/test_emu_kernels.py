@@ -93,6 +93,9 @@ def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
 @pytest.mark.parametrize("n_fft,hop,L,B", [
     (512, 128, 4000, 2), (2048, 512, 9000, 1), (400, 160, 3000, 2), (27, 5, 300, 1),
     (30, 7, 300, 2), (8192, 2048, 20000, 1),
+    # 3 clips x 22 frames on 2 workgroups: carried sector-aligned windows across groups, a clip
+    # change inside a stretch, odd and even T
+    (2048, 512, 10752, 3), (2048, 512, 11300, 2),
 ])
 def test_emu_istft(n_fft, hop, L, B):
     rng = np.random.default_rng(n_fft)

@@ -65,6 +65,18 @@ def test_stft_2048_many_groups(B, L, pad_mode):
     np.testing.assert_allclose(host(S), R, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,L", [(40, 44100), (24, 60001), (300, 9000)])
+def test_istft_2048_many_groups(B, L):
+    """n_fft=2048 irfft wave kernel with more groups than workgroups (carried sector-aligned row
+    windows, clip changes inside a stretch): frames against numpy's irfft, then the round trip."""
+    rng = np.random.default_rng(L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ao.stft(y, n_fft=2048, hop_length=512)
+    out = ap.istft(dev(S.astype(np.complex64)), hop_length=512, length=L)
+    np.testing.assert_allclose(host(out), ao.istft(S, hop_length=512, n_fft=2048, length=L), atol=2e-5)
+    np.testing.assert_allclose(host(out)[:, 1024:-2048], y[:, 1024:-2048], atol=2e-5)
+
+
 @pytest.mark.parametrize("pad_mode", ["constant", "reflect", "edge"])
 @pytest.mark.parametrize("center", [True, False])
 def test_stft_pad_modes(random_signal, pad_mode, center):
