@@ -182,8 +182,11 @@ int ap_irfft_frames_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, 
 
 /* istft core: irfft + window + overlap-add + sum(w^2) normalise + trim.
  *   out[b,i] = OLA(position i + out_offset), i in [0,out_len)
- *   frames_ws : caller-provided workspace of B*T*n_fft floats.
+ *   frames_ws : caller-provided workspace of ap_istft_workspace_floats(...) floats (B*T*n_fft
+ *               in general; 0 — the pointer may then be NULL — when the fused n_fft = 2048
+ *               kernel applies: the frames stay in LDS and never reach HBM).
  * Length logic (stft.py:300-338) stays in the caller. */
+int64_t ap_istft_workspace_floats(int64_t B, int64_t T, int n_fft, int hop, int64_t out_offset);
 int ap_istft_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, int n_fft, int hop,
                  const float *window /*dev*/, const float *tw /*dev*/, float *frames_ws /*dev*/,
                  int64_t out_offset, int64_t out_len, float *out /*dev (B,out_len)*/,

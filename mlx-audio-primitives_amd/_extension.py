@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ap_mel_filterbank_host", "ap_dct_matrix_host", "ap_twiddle_table_host", "ap_fft_supported",
     "ap_mel_plan_words", "ap_mel_plan_host",
     "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
-    "ap_stft_f32", "ap_melspec_f32", "ap_irfft_frames_f32", "ap_istft_f32",
+    "ap_stft_f32", "ap_melspec_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_workspace_floats",
     "ap_magnitude_f32", "ap_phase_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
@@ -104,6 +104,8 @@ def _declare(lib) -> None:
         fn.restype = I
     lib.ap_mel_plan_words.argtypes = [P, I, I]
     lib.ap_mel_plan_words.restype = L
+    lib.ap_istft_workspace_floats.argtypes = [L, L, I, I, L]
+    lib.ap_istft_workspace_floats.restype = L
 
 
 def _load() -> None:

@@ -348,6 +348,38 @@ static inline int ap_prepare_irfft_wave(ApIrfftWaveParams &W, const ApIrfftParam
     return AP_OK;
 }
 
+// fused irfft + overlap-add geometry (ap_istft_f32, n_fft = 2048): returns 1 when the fused kernel
+// does not apply (hop shape, tiny problems where the one-group warm-up of a stretch would cost
+// more than the separate overlap-add pass, LDS)
+static inline bool ap_istft_fused_shape(int64_t B, int64_t T, int n_fft, int hop, int64_t out_offset) {
+    if (n_fft != 2048 || B <= 0 || T <= 0 || T > (1 << 20)) return false;
+    if (hop < 256 || hop > 2048 || 2048 % hop != 0) return false;
+    if (out_offset % 4 != 0) return false;
+    return ((T + APS_WAVES - 1) / APS_WAVES) * B >= 64;
+}
+
+static inline int ap_prepare_istft_wave(ApIrfftWaveParams &W, const ApIrfftParams &P, int64_t B,
+                                        const float *window, int hop, int64_t out_offset,
+                                        int64_t out_len, float *y, int *grid) {
+    int g0 = 0;
+    if (!ap_istft_fused_shape(B, P.T, 2048, hop, out_offset)) return 1;
+    if (ap_prepare_irfft_wave(W, P, B, &g0) != AP_OK) return 1;
+    W.window = window;
+    W.y = y;
+    W.hop = hop;
+    W.out_offset = out_offset;
+    W.out_len = out_len;
+    int off = W.lds_bytes;
+    W.off_win = off; off += 2048 * (int)sizeof(float);
+    W.off_carry = off; off += 2 * (2048 - hop) * (int)sizeof(float);
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    int64_t g = W.n_groups / 4;                            // >= 4 groups per stretch
+    if (g > 256) g = 256;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 static inline int ap_prepare_irfft(ApIrfftParams &P, const float *S, int64_t B, int64_t T, int n_fft,
                                    const float *tw, float *frames) {
     if (!S || !tw || !frames) AP_FAIL(AP_ERR_INVALID, "irfft: NULL buffer");

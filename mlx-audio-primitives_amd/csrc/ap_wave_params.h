@@ -47,7 +47,14 @@ struct ApStftWaveParams {
 struct ApIrfftWaveParams {
     const ap_float2 *S;        // (B, 1025, T)
     const ap_float2 *tw;       // (2048)
-    float *frames;             // (B, T, 2048)
+    float *frames;             // (B, T, 2048)                       [irfft only]
     int64_t T, groups_per_clip, n_groups;
     int off_tw2, off_tw1, off_ob, lds_bytes;
+    // fused overlap-add (ap_istft_f32): y[b, i] = sum_t w[s] frame_t[s] / max(sum_t w[s]^2, 1e-8),
+    // s = i + out_offset - t hop
+    const float *window;       // (2048) synthesis window
+    float *y;                  // (B, out_len)
+    int64_t out_offset, out_len;
+    int hop;                   // 2048 % hop == 0, hop % 4 == 0, hop >= 256
+    int off_win, off_carry;    // LDS: window table, two carry buffers of 2048 - hop floats
 };

@@ -196,9 +196,9 @@ int ap_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const f
         ApIrfftWaveParams W;
         int grid = 0;
         if (ap_prepare_irfft_wave(W, P, B, &grid) == AP_OK) {
-            rc = ap_allow_lds(ap_irfft2048_wave_kernel, W.lds_bytes);
+            rc = ap_allow_lds(ap_irfft2048_wave_kernel<0>, W.lds_bytes);
             if (rc != AP_OK) return rc;
-            hipLaunchKernelGGL(ap_irfft2048_wave_kernel, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
+            hipLaunchKernelGGL(ap_irfft2048_wave_kernel<0>, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
                                (hipStream_t)stream, W);
             return ap_check_launch("ap_irfft_frames_f32(wave)");
         }
@@ -210,9 +210,29 @@ int ap_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const f
     return ap_check_launch("ap_irfft_frames_f32");
 }
 
+int64_t ap_istft_workspace_floats(int64_t B, int64_t T, int n_fft, int hop, int64_t out_offset) {
+    if (B <= 0 || T <= 0 || n_fft <= 0) return 0;
+    return ap_istft_fused_shape(B, T, n_fft, hop, out_offset) ? 0 : B * T * (int64_t)n_fft;
+}
+
 int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const float *window,
                  const float *tw, float *frames_ws, int64_t out_offset, int64_t out_len, float *out,
                  void *stream) {
+    if (n_fft == 2048 && window && out && hop > 0 && out_len > 0) {
+        // fused irfft + overlap-add: the (B, T, n_fft) frames never reach HBM
+        ApIrfftParams P;
+        int rc0 = ap_prepare_irfft(P, S, B, T, n_fft, tw, out /* frames pointer unused */);
+        if (rc0 != AP_OK) return rc0;
+        ApIrfftWaveParams W;
+        int grid = 0;
+        if (ap_prepare_istft_wave(W, P, B, window, hop, out_offset, out_len, out, &grid) == AP_OK) {
+            rc0 = ap_allow_lds(ap_irfft2048_wave_kernel<1>, W.lds_bytes);
+            if (rc0 != AP_OK) return rc0;
+            hipLaunchKernelGGL(ap_irfft2048_wave_kernel<1>, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
+                               (hipStream_t)stream, W);
+            return ap_check_launch("ap_istft_f32(fused)");
+        }
+    }
     if (!frames_ws) AP_FAIL(AP_ERR_INVALID, "istft: NULL workspace");
     int rc = ap_irfft_frames_f32(S, B, T, n_fft, tw, frames_ws, stream);
     if (rc != AP_OK) return rc;

@@ -559,6 +559,17 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
 // its own frame's bins k = lane + 64 r and 1024 - k in registers; Hermitian merge, the
 // same 16 x 16 x 4 transform on conjugated data, and 128-byte-coalesced stores straight
 // from the quad outputs (no second LDS transpose).
+//
+// OLA = 1 (ap_istft_f32): the frames never leave the workgroup.  Every wave leaves its windowed
+// frame in its own exchange buffer; after one barrier the 512 threads gather the 8 hop output
+// positions the group completes (those whose last contributing frame is in the group) — 16-byte
+// LDS reads of the <= n_fft/hop frames that cover them, in increasing frame order like
+// overlap_add.metal:16-55 — divide by the window-sum-of-squares of the frames that exist, and
+// store them; what the group contributes to later positions goes into an LDS carry (two buffers,
+// ping-pong) that the next group of the workgroup's contiguous stretch starts from.  A stretch
+// that begins inside a clip first runs the preceding group with its stores disabled to rebuild
+// the carry; the tail after a clip's last group is emitted from the carry positions.
+template <int OLA>
 __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(ApIrfftWaveParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -572,6 +583,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
         ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
         if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = P.tw[32 * (tid >> 4) * (tid & 15)];
         for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
+        if (OLA) {
+            float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
+            for (int i = tid; i < 2 * APW_NC; i += 64 * APS_WAVES) win[i] = P.window[i];
+        }
     }
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     AP_LDS_BARRIER();
@@ -602,8 +617,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
             }
         if (tid < APS_WAVES) pre_mid = live ? sb[(APW_NC / 2) * Ti] : ap_mk(0.0f, 0.0f);
     };
-    if (g_lo < g_hi) load_group(g_lo);
-    for (int64_t group = g_lo; group < g_hi; ++group) {
+    // OLA: a stretch that starts inside a clip begins one group early (stores disabled)
+    const int64_t g_first = (OLA && g_lo < g_hi && g_lo % P.groups_per_clip != 0) ? g_lo - 1 : g_lo;
+    if (g_first < g_hi) load_group(g_first);
+    for (int64_t group = g_first; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;
         const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
         const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
@@ -652,13 +669,85 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
         AP_WAVE_SYNC();
         apw_forward<false>(v, X, TW1, lc);
         // y[n] = conj(Y[n]) / 2048 -> samples 2n, 2n+1;  n = k1p + 16 c + 256 qd
-        if (wave < Gt) {
-            float *dst = P.frames + ((b * P.T + t0 + wave) * (int64_t)2048);
+        if (!OLA) {
+            if (wave < Gt) {
+                float *dst = P.frames + ((b * P.T + t0 + wave) * (int64_t)2048);
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    const int n = lc.k1p + 16 * cc + 256 * lc.qd;
+                    *reinterpret_cast<ap_float2 *>(dst + 2 * n) = ap_mul2(v[cc], ap_mk(scale, -scale));
+                }
+            }
+            continue;
+        }
+        // ---- fused overlap-add ---------------------------------------------------------------
+        const int H = P.hop;
+        const int CN = 2 * APW_NC - H;                              // carry length
+        const ap_float2 *WINP = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // (w[2n], w[2n+1])
+        const float *WIN = reinterpret_cast<const float *>(ap_smem + P.off_win);
+        float *carry_in = reinterpret_cast<float *>(ap_smem + P.off_carry) + (int)(group & 1) * CN;
+        float *carry_out = reinterpret_cast<float *>(ap_smem + P.off_carry) + (int)((group + 1) & 1) * CN;
+        {   // windowed frame -> this wave's exchange buffer (padded natural order: conflict-free)
+            ap_float2 wv[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) wv[cc] = WINP[lc.k1p + 16 * cc + 256 * lc.qd];
+            AP_WAVE_SYNC();                                          // quad stage done with X
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) {
                 const int n = lc.k1p + 16 * cc + 256 * lc.qd;
-                *reinterpret_cast<ap_float2 *>(dst + 2 * n) = ap_mul2(v[cc], ap_mk(scale, -scale));
+                X[apw_zidx(n)] = ap_mul2(ap_mul2(v[cc], ap_mk(scale, -scale)), wv[cc]);
             }
+        }
+        if (t0 == 0)                                                 // a clip starts: nothing carried in
+            for (int i = tid; i < CN; i += 64 * APS_WAVES) carry_in[i] = 0.0f;
+        AP_LDS_BARRIER();
+        const bool emit = group >= g_lo;                             // not the warm-up group
+        const bool clip_last = t0 + APS_WAVES >= P.T;
+        const float *XF = reinterpret_cast<const float *>(ap_smem);  // frame f at XF + f * 2 APW_X_COMPLEX
+        const int n_own = APS_WAVES * H;                             // positions this group completes
+        const int64_t p0 = t0 * (int64_t)H;                          // padded position of r = 0
+        float *yb = P.y + b * P.out_len;
+        for (int r = 4 * tid; r < n_own + CN; r += 4 * 64 * APS_WAVES) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            if (r < CN) {
+                const ap_float4 c4 = *reinterpret_cast<const ap_float4 *>(carry_in + r);
+                s0 = c4.x; s1 = c4.y; s2 = c4.z; s3 = c4.w;
+            }
+            const int f_lo = r < 2 * APW_NC ? 0 : (r - 2 * APW_NC) / H + 1;
+            int f_hi = r / H;
+            if (f_hi > APS_WAVES - 1) f_hi = APS_WAVES - 1;
+            for (int f = f_lo; f <= f_hi; ++f) {
+                const int sidx = r - f * H;                          // sample index in frame f (multiple of 4)
+                const ap_float4 q = *reinterpret_cast<const ap_float4 *>(
+                    XF + f * (2 * APW_X_COMPLEX) + 2 * apw_zidx(sidx >> 1));
+                s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+            }
+            if (r >= n_own) {                                        // contributions to the next group's range
+                ap_float4 c4; c4.x = s0; c4.y = s1; c4.z = s2; c4.w = s3;
+                *reinterpret_cast<ap_float4 *>(carry_out + (r - n_own)) = c4;
+            }
+            if (emit && (r < n_own || clip_last)) {
+                const int64_t p = p0 + r;
+                // window-sum-of-squares over the frames of the clip that cover p
+                int64_t F_lo = p < 2 * APW_NC ? 0 : (p - 2 * APW_NC) / H + 1;
+                int64_t F_hi = p / H;
+                if (F_hi > P.T - 1) F_hi = P.T - 1;
+                float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, w3 = 0.0f;
+                for (int64_t Fi = F_lo; Fi <= F_hi; ++Fi) {
+                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (int)(p - Fi * H));
+                    w0 += w.x * w.x; w1 += w.y * w.y; w2 += w.z * w.z; w3 += w.w * w.w;
+                }
+                const int64_t n = p - P.out_offset;
+                if (n >= 0 && n < P.out_len) yb[n] = s0 / fmaxf(w0, 1e-8f);
+                if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
+                if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
+                if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+            }
+        }
+        if (emit && clip_last) {                                     // no frame reaches beyond the tail: 0 / 1e-8
+            int64_t n = p0 + n_own + CN - P.out_offset;
+            if (n < 0) n = 0;
+            for (n += tid; n < P.out_len; n += 64 * APS_WAVES) yb[n] = 0.0f;
         }
     }
 }

@@ -91,7 +91,8 @@ def griffinlim(S, n_iter: int = 32, hop_length: int | None = None, win_length: i
     rebuilt = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
     tprev = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
     R = torch.empty((B, F, TR, 2), dtype=torch.float32, device=dev)
-    ws = torch.empty((B, T, n_fft), dtype=torch.float32, device=dev)
+    n_ws = int(_x.lib().ap_istft_workspace_floats(B, T, int(n_fft), int(hop_length), pad))
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
     y = torch.empty((B, y_len), dtype=torch.float32, device=dev)
     _x.check(_x.lib().ap_griffinlim_f32(
         _x.ptr(S), _x.ptr(angles), B, T, int(n_fft), int(hop_length), _x.ptr(win), _x.ptr(tw),

@@ -189,7 +189,9 @@ def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = N
         torch.empty((B, out_len), dtype=torch.float32, device=dev)
     if B > 0 and T > 0 and ola_len > 0:
         tw = _get_twiddles(n_fft, dev)
-        ws = torch.empty((B, T, n_fft), dtype=torch.float32, device=dev)
+        # (B, T, n_fft) frames workspace; 0 floats when the fused irfft + overlap-add kernel applies
+        n_ws = int(_x.lib().ap_istft_workspace_floats(B, T, int(n_fft), int(hop_length), offset))
+        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
         Sr = torch.view_as_real(S)
         if ola_len == out_len:
             tgt = y

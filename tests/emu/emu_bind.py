@@ -224,6 +224,19 @@ def dct(x, C, outer, n_in, inner, row_scale=None, db=None):
     return out
 
 
+def istft_fused(S, hop, window, out_len, out_offset=1024, grid_cap=0):
+    """ap_irfft2048_wave_kernel<1>: irfft + overlap-add of an n_fft = 2048 spectrum (B, 1025, T)."""
+    S = np.ascontiguousarray(S, np.complex64)
+    B, F, T = S.shape
+    Sv = np.ascontiguousarray(S.view(np.float32))
+    out = np.zeros((B, out_len), np.float32)
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(2048)
+    _check(lib().emu_istft_fused_f32(_p(Sv), _i64(B), _i64(T), hop, _p(window), _p(tw), _i64(out_offset),
+                                     _i64(out_len), grid_cap, _p(out)))
+    return out
+
+
 def cfft_split(N):
     a, b = ctypes.c_int(0), ctypes.c_int(0)
     rc = lib().emu_cfft_split(_i64(N), ctypes.byref(a), ctypes.byref(b))

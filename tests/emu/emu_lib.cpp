@@ -127,7 +127,7 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
         int grid = 0;
         if (ap_prepare_irfft_wave(W, P, B, &grid) == AP_OK) {
             if (grid > 2) grid = 2;
-            emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel(W); });
+            emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<0>(W); });
             return AP_OK;
         }
     }
@@ -170,6 +170,31 @@ int emu_gl_project_f32(int mode, const float *S, const float *angles, const floa
         ap_gl_project_kernel(mode, S, angles, reinterpret_cast<const ap_float2 *>(R), TR, BF, T, momentum,
                              reinterpret_cast<ap_float2 *>(tprev), reinterpret_cast<ap_float2 *>(rebuilt));
     });
+    return AP_OK;
+}
+
+// fused irfft + overlap-add (n_fft = 2048); grid_cap > 0 limits the workgroups so stretches get long
+int emu_istft_fused_f32(const float *S, int64_t B, int64_t T, int hop, const float *window, const float *tw,
+                        int64_t out_offset, int64_t out_len, int grid_cap, float *out) {
+    ApIrfftParams P;
+    int rc = ap_prepare_irfft(P, S, B, T, 2048, tw, out /* unused frames pointer, non-NULL */);
+    if (rc != AP_OK) return rc;
+    ApIrfftWaveParams W;
+    int grid = 0;
+    if (ap_prepare_istft_wave(W, P, B, window, hop, out_offset, out_len, out, &grid) != AP_OK) {
+        // below the product's size threshold: still run the fused kernel for coverage
+        int g0 = 0;
+        if (ap_prepare_irfft_wave(W, P, B, &g0) != AP_OK) return AP_ERR_UNSUPPORTED;
+        if (hop < 256 || 2048 % hop != 0 || out_offset % 4 != 0) return AP_ERR_UNSUPPORTED;
+        W.window = window; W.y = out; W.hop = hop; W.out_offset = out_offset; W.out_len = out_len;
+        int off = W.lds_bytes;
+        W.off_win = off; off += 2048 * 4;
+        W.off_carry = off; off += 2 * (2048 - hop) * 4;
+        W.lds_bytes = off;
+        grid = (int)(W.n_groups < 256 ? W.n_groups : 256);
+    }
+    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+    emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<1>(W); });
     return AP_OK;
 }
 

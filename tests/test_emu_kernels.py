@@ -111,6 +111,20 @@ def test_emu_istft(n_fft, hop, L, B):
         assert np.max(np.abs(out - y)) < 1e-5        # README.md:118
 
 
+@pytest.mark.parametrize("hop,L,B,grid_cap", [(512, 10752, 3, 2), (512, 11300, 2, 3), (1024, 30000, 2, 2),
+                                              (256, 9000, 1, 2), (512, 6000, 1, 0)])
+def test_emu_istft_fused(hop, L, B, grid_cap):
+    """Fused irfft + overlap-add kernel: carries across the groups of a stretch, warm-up group of a
+    stretch that starts inside a clip, clip change inside a stretch, tail after the last group."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ao.stft(y, n_fft=2048, hop_length=hop)
+    win = ao.padded_window("hann", 2048, 2048)
+    for length in (L, L - 700):
+        out = eb.istft_fused(S, hop, win, length, grid_cap=grid_cap)
+        np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=2048, length=length), atol=1e-5)
+
+
 def test_emu_irfft_ignores_dc_nyquist_imag():
     rng = np.random.default_rng(5)
     S = (rng.standard_normal((1, 33, 4)) + 1j * rng.standard_normal((1, 33, 4))).astype(np.complex64)

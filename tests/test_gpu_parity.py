@@ -77,6 +77,28 @@ def test_istft_2048_many_groups(B, L):
     np.testing.assert_allclose(host(out)[:, 1024:-2048], y[:, 1024:-2048], atol=2e-5)
 
 
+@pytest.mark.parametrize("hop", [256, 512, 1024])
+def test_istft_fused_hops_and_lengths(hop):
+    """Fused irfft + overlap-add (n_fft=2048, >= 64 groups): hop 256 / 512 / 1024, natural length,
+    a shorter one and one beyond the last frame (zero tail), center on and off."""
+    rng = np.random.default_rng(hop)
+    B, L = 16, 66150
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    for center in (True, False):
+        S = ao.stft(y, n_fft=2048, hop_length=hop, center=center)
+        Sd = dev(S.astype(np.complex64))
+        for length in (None, L - 1000, L + 3000):
+            got = host(ap.istft(Sd, hop_length=hop, center=center, length=length))
+            want = ao.istft(S, hop_length=hop, n_fft=2048, center=center, length=length)
+            assert got.shape == want.shape
+            # where the frames end sum(w^2) falls to the 1e-8 floor and float32 noise is amplified:
+            # compare 128 samples inside the ends of the frames, then the exact zero tail
+            T = S.shape[-1]
+            end = (T - 1) * hop + 2048 - (1024 if center else 0)
+            np.testing.assert_allclose(got[:, 128:end - 128], want[:, 128:end - 128], atol=2e-5)
+            assert not got[:, end:].any() and np.isfinite(got).all()
+
+
 @pytest.mark.parametrize("pad_mode", ["constant", "reflect", "edge"])
 @pytest.mark.parametrize("center", [True, False])
 def test_stft_pad_modes(random_signal, pad_mode, center):
