@@ -595,35 +595,51 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
 
     const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
     const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    // thread (sq = tid / 8, sf = tid % 8) fetches frame sf of rows sq, 64 + sq, 128 + sq, 192 + sq of
-    // every chunk (bins 64 r + sq and 1024 - 64 r - sq, r = 2c, 2c + 1) -- the whole group one
-    // iteration ahead, into registers, so that HBM latency is paid under the previous transform
-    // and not once per chunk
+    // thread (sq = tid / 8, sf = tid % 8) fetches rows sq, 64 + sq, 128 + sq, 192 + sq of every
+    // chunk (bins 64 r + sq and 1024 - 64 r - sq, r = 2c, 2c + 1) in SECTOR-ALIGNED windows of 8
+    // frames, like the STFT kernel stores them: with T odd a segment S[b, k, t0..t0+7] straddles
+    // two 64-byte sectors for 7 rows out of 8 and the kernel fetched 2.7 x its input.  Row k's
+    // window g is [t0 + phi - 8, t0 + phi), phi(k) = frames from t0 to the row's next 64-byte
+    // boundary; the 8 frames of a group are the tail of window g (carry `wa`, loaded one group
+    // earlier) and the head of window g + 1 (`wb`, prefetched under the previous transform), picked
+    // with one select per element.
     const int sq = tid >> 3, sf = tid & 7;
-    const int Ti = (int)P.T;
-    ap_float2 pre[4][4], pre_mid = ap_mk(0.0f, 0.0f);
-    auto load_group = [&](int64_t group) {
-        const int64_t b = group / P.groups_per_clip;
-        const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
-        const bool live = t0 + sf < P.T;
-        const ap_float2 *sb = P.S + b * (int64_t)F * P.T + t0 + sf;
+    const int Ti = (int)P.T, T7 = (int)(P.T & 7);
+    ap_float2 wa[4][4], wb[4][4], wa_mid = ap_mk(0.0f, 0.0f), wb_mid = ap_mk(0.0f, 0.0f);
+    auto clip_phase = [&](int64_t b) {      // (complex index of S[b, 0, 0]) mod 8
+        return (int)(((reinterpret_cast<uintptr_t>(P.S) >> 3) + (uint64_t)(b * (int64_t)F * P.T)) & 7);
+    };
+    // the window of every row that starts phi(row) + dt0 frames after frame 0 of clip b
+    auto load_window = [&](ap_float2 (&w)[4][4], ap_float2 &wmid, int64_t b, int64_t dt0) {
+        const int a0 = clip_phase(b);
+        const ap_float2 *sb = P.S + b * (int64_t)F * P.T;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 2 * c + (i >> 1);
                 const int bin = (i & 1) ? APW_NC - 64 * r - sq : 64 * r + sq;
-                pre[c][i] = live ? sb[bin * Ti] : ap_mk(0.0f, 0.0f);
+                const int64_t t = dt0 + ((0 - (a0 + bin * T7)) & 7) + sf;
+                w[c][i] = (t >= 0 && t < P.T) ? sb[bin * Ti + (int)t] : ap_mk(0.0f, 0.0f);
             }
-        if (tid < APS_WAVES) pre_mid = live ? sb[(APW_NC / 2) * Ti] : ap_mk(0.0f, 0.0f);
+        if (tid < APS_WAVES) {
+            const int64_t t = dt0 + ((0 - (a0 + (APW_NC / 2) * T7)) & 7) + sf;
+            wmid = (t >= 0 && t < P.T) ? sb[(APW_NC / 2) * Ti + (int)t] : ap_mk(0.0f, 0.0f);
+        }
     };
     // OLA: a stretch that starts inside a clip begins one group early (stores disabled)
     const int64_t g_first = (OLA && g_lo < g_hi && g_lo % P.groups_per_clip != 0) ? g_lo - 1 : g_lo;
-    if (g_first < g_hi) load_group(g_first);
+    if (g_first < g_hi) {
+        const int64_t b = g_first / P.groups_per_clip;
+        const int64_t t0 = (g_first - b * P.groups_per_clip) * APS_WAVES;
+        load_window(wa, wa_mid, b, t0 - 8);
+        load_window(wb, wb_mid, b, t0);
+    }
     for (int64_t group = g_first; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;
         const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
         const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
+        const int a0 = clip_phase(b);                   // t0 is a multiple of 8
 
         // ---- transpose through LDS: every wave collects its frame's bins in registers -------
         ap_float2 xk[8], xm[8], xh = ap_mk(0.0f, 0.0f);
@@ -631,9 +647,18 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
         for (int c = 0; c < 4; ++c) {
             ap_float2 *buf = IB + (c & 1) * (APS_OB_ROWS * APS_OB_ROW);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                buf[((i >> 1) * 128 + (i & 1) * 64 + sq) * APS_OB_ROW + sf] = pre[c][i];
-            if (c == 3 && tid < APS_WAVES) buf[256 * APS_OB_ROW + sf] = pre_mid;
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * c + (i >> 1);
+                const int bin = (i & 1) ? APW_NC - 64 * r - sq : 64 * r + sq;
+                const int phi = (0 - (a0 + bin * T7)) & 7;
+                // position sf of the windows holds frame (sf + phi) mod 8 of this group
+                buf[((i >> 1) * 128 + (i & 1) * 64 + sq) * APS_OB_ROW + ((sf + phi) & 7)] =
+                    sf < 8 - phi ? wb[c][i] : wa[c][i];
+            }
+            if (c == 3 && tid < APS_WAVES) {
+                const int phi = (0 - (a0 + (APW_NC / 2) * T7)) & 7;
+                buf[256 * APS_OB_ROW + ((sf + phi) & 7)] = sf < 8 - phi ? wb_mid : wa_mid;
+            }
             AP_LDS_BARRIER();
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -643,7 +668,20 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
             if (c == 3) xh = buf[256 * APS_OB_ROW + wave];
         }
         AP_SCHED_FENCE();
-        if (group + 1 < g_hi) load_group(group + 1);
+        if (group + 1 < g_hi) {
+            const int64_t bn = (group + 1) / P.groups_per_clip;
+            const int64_t tn = (group + 1 - bn * P.groups_per_clip) * APS_WAVES;
+            if (bn == b) {                               // same clip: window g + 1 becomes the carry
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wa[c][i] = wb[c][i];
+                wa_mid = wb_mid;
+            } else {
+                load_window(wa, wa_mid, bn, tn - 8);
+            }
+            load_window(wb, wb_mid, bn, tn);
+        }
         AP_SCHED_FENCE();
         // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[1024-k]) / 2 of the packed inverse -----
         //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = (W^-k / 2) d
