@@ -197,6 +197,8 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.quads = reinterpret_cast<const float *>(plan + desc[13]);
     W.n_quads = desc[14];
     W.n_slots = desc[7];
+    W.max_row_parts = desc[15];
+    W.partial_stride = (W.n_slots + 1 + 3 + 3) & ~3;
     W.rowstart = plan + desc[10];
     W.out = P.out_mel;
     W.L = P.L;
@@ -216,7 +218,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.off_wq = off; off += ap_align16(W.n_quads * 16);
     // part descriptors beyond the APW_PASSES register-resident passes are read from LDS
     W.off_parts = off; off += W.n_parts > 64 * APW_PASSES ? ap_align16(W.n_parts * 16) : 0;
-    W.off_partial = off; off += ap_align16(n_waves * W.n_slots * 4);
+    W.off_partial = off; off += ap_align16(n_waves * W.partial_stride * 4);
     W.otile_stride = ((M + 27) / 32) * 32 + 4;              // >= M and = 4 (mod 32): conflict-free both ways
     W.off_otile = off; off += ap_align16(n_waves * W.otile_stride * APW_G * 4);
     W.lds_bytes = off;

@@ -23,6 +23,8 @@ struct ApMelWaveParams {
     float *out;                // (B, M, T)
     int64_t L, T, tiles_per_clip, n_tiles, n_clips;
     int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots;   // n_slots: partial sums per frame
+    int max_row_parts;         // largest number of parts of one row
+    int partial_stride;        // floats between the waves' partial-sum arrays (n_slots + dump slot + 3 read-ahead)
     float power;
     // LDS carve-up (bytes from the start of dynamic LDS)
     int off_tw2, off_tw1, off_win, off_wq, off_parts, off_partial, off_otile, lds_bytes;

@@ -230,7 +230,11 @@ void mel_wave_layout(const std::vector<MelPart> &parts, MelWaveLayout &L) {
     const int passes = (n + 63) / 64;
     L.entry.assign((size_t)passes * 64, -1);
     L.qw.assign((size_t)passes * 64, 0);
-    int block = 0;                                     // 64-quad rows used so far
+    // every pass owns four 64-quad rows whatever its longest part is, and every entry (idle lanes
+    // too) points at its own column of them: the kernel reads 4 weight quads per lane without a
+    // branch and the ones past a part's end are zero
+    for (int ps = 0; ps < passes; ++ps)
+        for (int lane = 0; lane < 64; ++lane) L.qw[(size_t)ps * 64 + lane] = ps * 256 + lane;
     for (int ps = 0; ps < passes; ++ps) {
         const int first = ps * 64, last = first + 64 < n ? first + 64 : n;
         std::vector<int> bucket[16];
@@ -254,17 +258,11 @@ void mel_wave_layout(const std::vector<MelPart> &parts, MelWaveLayout &L) {
                 has[best][r]++;
             }
         }
-        int max_ng = 0;
         for (int g = 0; g < 4; ++g)
-            for (size_t j = 0; j < grp[g].size(); ++j) {
-                const int lane = kB128Groups[g][j];
-                L.entry[(size_t)ps * 64 + lane] = grp[g][j];
-                L.qw[(size_t)ps * 64 + lane] = block * 64 + lane;
-                if (parts[grp[g][j]].ng > max_ng) max_ng = parts[grp[g][j]].ng;
-            }
-        block += max_ng;
+            for (size_t j = 0; j < grp[g].size(); ++j)
+                L.entry[(size_t)ps * 64 + kB128Groups[g][j]] = grp[g][j];
     }
-    L.n_quads = block * 64;
+    L.n_quads = passes * 256;
 }
 }  // namespace
 
@@ -331,8 +329,17 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
             }
     }
     float *wwq = reinterpret_cast<float *>(plan + off_wquads);
+    int max_row_parts = 0;
+    for (int m = 0; m < M; ++m)
+        if (plan[off_rs + m + 1] - plan[off_rs + m] > max_row_parts)
+            max_row_parts = plan[off_rs + m + 1] - plan[off_rs + m];
     for (size_t e = 0; e < WL.entry.size(); ++e) {
-        if (WL.entry[e] < 0) continue;                       // idle lane: all-zero descriptor (ng = 0)
+        if (WL.entry[e] < 0) {
+            // idle lane: group 0 with all-zero weights, partial sum dumped past the last slot
+            plan[off_wparts + 4 * e + 0] = (int32_t)parts.size();
+            plan[off_wparts + 4 * e + 3] = WL.qw[e];
+            continue;
+        }
         const MelPart &p = parts[WL.entry[e]];
         plan[off_wparts + 4 * e + 0] = p.slot;
         plan[off_wparts + 4 * e + 1] = p.g0;
@@ -359,6 +366,7 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     desc[12] = (int32_t)WL.entry.size();
     desc[13] = (int32_t)off_wquads;
     desc[14] = (int32_t)WL.n_quads;
+    desc[15] = max_row_parts;
     return AP_OK;
 }
 

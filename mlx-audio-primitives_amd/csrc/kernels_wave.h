@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
     const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // [1024] pairs
     const ap_float4 *WQ = reinterpret_cast<const ap_float4 *>(ap_smem + P.off_wq);     // [n_quads]
     const ap_int4 *PART = reinterpret_cast<const ap_int4 *>(ap_smem + P.off_parts);    // [n_parts]
-    float *partial = reinterpret_cast<float *>(ap_smem + P.off_partial) + wave * P.n_slots;   // this wave's
+    float *partial = reinterpret_cast<float *>(ap_smem + P.off_partial) + wave * P.partial_stride;   // this wave's
     float *otile = reinterpret_cast<float *>(ap_smem + P.off_otile) + wave * P.otile_stride * APW_G;  // [APW_G][stride]
     const int M = P.n_mels;
 
@@ -328,28 +328,29 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             }
             AP_WAVE_SYNC();
             // ---- mel contraction of this frame by its own wave (no workgroup barrier) ----
-            // parts are sorted by length, so the 64 lanes of one pass run loops of ~equal length.
-            // The lane's part descriptors are frame-invariant (registers); all LDS reads of a pass
-            // are issued before the first FMA so a pass costs one LDS latency, not one per group.
+            // The lane's part descriptors are frame-invariant (registers).  No branch inside a pass:
+            // every lane reads 4 weight quads (zero past its part's end, all zero for an idle lane,
+            // whose sum goes to a dump slot) and 4 |X|^p quads, all 8 reads in flight together -
+            // with per-group branches the compiler fenced every read with an s_waitcnt.
 #pragma unroll
             for (int ps = 0; ps < APW_PASSES; ++ps) {
-                const ap_int4 pd = mypart[ps];                     // slot, g0, ng, q0 (ng = 0: idle)
-                const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
-                const ap_float4 *wq = WQ + pd.w;
-                ap_float4 w[4], q[4];
+                if (64 * ps < P.n_parts) {                         // wave-uniform
+                    const ap_int4 pd = mypart[ps];                 // slot, g0, ng, q0
+                    const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                    const ap_float4 *wq = WQ + pd.w;
+                    ap_float4 w[4], q[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < pd.z) { w[i] = wq[64 * i]; q[i] = pq[i]; }
-                float acc = 0.0f;
+                    for (int i = 0; i < 4; ++i) { w[i] = wq[64 * i]; q[i] = pq[i]; }
+                    float acc = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < pd.z) {
+                    for (int i = 0; i < 4; ++i) {
                         acc = fmaf(w[i].x, q[i].x, acc);
                         acc = fmaf(w[i].y, q[i].y, acc);
                         acc = fmaf(w[i].z, q[i].z, acc);
                         acc = fmaf(w[i].w, q[i].w, acc);
                     }
-                if (pd.z > 0) partial[pd.x] = acc;
+                    partial[pd.x] = acc;
+                }
             }
             for (int p0 = 64 * APW_PASSES; p0 < P.n_parts; p0 += 64) {   // plans with > 256 parts
                 const int pi = p0 + lane;
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
                         acc = fmaf(w.z, q.z, acc);
                         acc = fmaf(w.w, q.w, acc);
                     }
-                    if (pd.z > 0) partial[pd.x] = acc;
+                    partial[pd.x] = acc;
                 }
             }
             AP_WAVE_SYNC();
@@ -374,11 +375,17 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = lane + 64 * i;
-                if (row < M) {
-                    float sum = 0.0f;
-                    for (int j = rs0[i]; j < rs1[i]; ++j) sum += partial[j];
-                    otile[g * P.otile_stride + row] = sum;
-                }
+                // up to 4 adjacent slots read together (the ones past the row's end are discarded)
+                const int cnt = rs1[i] - rs0[i];
+                const float p0 = partial[rs0[i]], p1 = partial[rs0[i] + 1], p2 = partial[rs0[i] + 2],
+                            p3 = partial[rs0[i] + 3];
+                float sum = cnt > 0 ? p0 : 0.0f;
+                sum += cnt > 1 ? p1 : 0.0f;
+                sum += cnt > 2 ? p2 : 0.0f;
+                sum += cnt > 3 ? p3 : 0.0f;
+                if (P.max_row_parts > 4)                           // wave-uniform, rare
+                    for (int j = rs0[i] + 4; j < rs1[i]; ++j) sum += partial[j];
+                if (row < M) otile[g * P.otile_stride + row] = sum;
             }
             for (int row = lane + 128; row < M; row += 64) {       // n_mels > 128
                 const int a0 = P.rowstart[row], a1 = P.rowstart[row + 1];
