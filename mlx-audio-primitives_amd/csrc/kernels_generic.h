@@ -18,13 +18,16 @@
 
 // Sample p of the virtually padded clip (p relative to the unpadded clip, may be
 // negative or >= L).  Index remaps follow pad_signal.metal:30-38 / stft.py:441-468.
+// Branch-free on purpose (selects + one load): per-sample early returns made every call a
+// divergent region and the edge frames of the wave kernels ten times slower than the others.
 AP_DEV float ap_load_padded(const float *yb, int64_t L, int64_t p, int mode) {
-    if (p >= 0 && p < L) return yb[p];
-    if (mode == AP_PAD_CONSTANT) return 0.0f;
-    if (mode == AP_PAD_EDGE) return yb[p < 0 ? 0 : L - 1];
+    const bool out = p < 0 || p >= L;
     int64_t q = p < 0 ? -p : 2 * (L - 1) - p;   // reflect, edge sample not repeated
-    q = q < 0 ? 0 : (q >= L ? L - 1 : q);       // host validates pad <= L-1; clamp is a guard only
-    return yb[q];
+    if (mode != AP_PAD_REFLECT) q = p;           // wave-uniform
+    q = q < 0 ? 0 : (q >= L ? L - 1 : q);       // edge: clamp; reflect: host validates pad <= L-1, guard only
+    if (!out) q = p;
+    const float v = yb[q];
+    return (out && mode == AP_PAD_CONSTANT) ? 0.0f : v;
 }
 
 AP_DEV float ap_pow_mag(float re, float im, float power) {

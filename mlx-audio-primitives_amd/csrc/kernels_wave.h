@@ -279,14 +279,21 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
         const float *yb = P.y + b * P.L;
         const ApClip clip = ap_clip_make(yb, P.L);
         const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
+        // edge / reflect padding only touches the frames that overlap a clip boundary: every
+        // other frame takes the same bounds-checked loads as the constant-padding kernel
+        const bool inside = !PADGEN || (base >= 0 && base + 2 * APW_NC <= P.L);
+        if (inside) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int64_t p = base + 2 * (lane + 64 * j);
-            if (PADGEN)
-                raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode),
-                               ap_load_padded(yb, P.L, p + 1, P.pad_mode));
-            else
+            for (int j = 0; j < 16; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
                 raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
+                raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            }
         }
     };
     if (f_lo < f_hi) load_frame(f_lo);
@@ -455,16 +462,21 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
         const float *yb = P.y + b * P.L;
         const ApClip clip = ap_clip_make(yb, P.L);
         const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
-        // frames beyond T read past the clip: zeros (constant) or clamped garbage (never stored)
+        // frames beyond T read past the clip: zeros (never stored).  Edge / reflect padding only
+        // touches the frames that overlap a clip boundary.
+        const bool inside = !PADGEN || t >= P.T || (base >= 0 && base + 2 * APW_NC <= P.L);
+        if (inside) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int64_t p = base + 2 * (lane + 64 * j);
-            if (PADGEN)
-                raw[j] = t < P.T ? ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode),
-                                         ap_load_padded(yb, P.L, p + 1, P.pad_mode))
-                                 : ap_mk(0.0f, 0.0f);
-            else
+            for (int j = 0; j < 16; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
                 raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
+                raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            }
         }
     };
     // every workgroup owns a contiguous stretch of the (clip, 8-frame group) stream: the 64-byte
