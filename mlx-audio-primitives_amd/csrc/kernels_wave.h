@@ -485,13 +485,16 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
     // every segment leaves as a partial line)
     const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
     const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    if (g_lo < g_hi) load_frame(g_lo);
+    // the edge / reflect instantiation does not prefetch: with both loaders live the 32 extra
+    // registers spill inside the store phase, and the kernel is bound by its stores anyway
+    if (!PADGEN && g_lo < g_hi) load_frame(g_lo);
 
     for (int64_t group = g_lo; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;
         const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
         const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
         ap_float2 *ob = P.out + b * (int64_t)F * P.T + t0;
+        if (PADGEN) load_frame(group);
         // (complex index of out[b, 0, t0]) mod 8: the same for every group of a clip
         const int a0 = (int)(((reinterpret_cast<uintptr_t>(P.out) >> 3) + (uint64_t)(b * (int64_t)F * P.T + t0)) & 7);
         const bool have_prev = group > g_lo && t0 > 0;          // carries hold this clip's previous group
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
             for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], w[j]);
         }
         AP_SCHED_FENCE();
-        if (group + 1 < g_hi) load_frame(group + 1);                         // next group's frame
+        if (!PADGEN && group + 1 < g_hi) load_frame(group + 1);              // next group's frame
         AP_SCHED_FENCE();
         ap_float2 xk[8], xm[8], zh;
         apw_forward(v, X, TW1, lc);
