@@ -308,6 +308,25 @@ int ap_griffinlim_f32(const float *S, const float *angles, int64_t B, int64_t T,
     const int64_t F = n_fft / 2 + 1;
     int rc = ap_gl_project_f32(0, S, angles, nullptr, 0, B * F, T, 0.0f, tprev, rebuilt, stream);
     if (rc != AP_OK) return rc;
+    if (TR == T) {
+        // raw STFT ping-pong: `tprev` starts as the initial estimate and then alternates with `R`
+        // as the previous / current raw spectrum; the projection never writes tprev back
+        float *raw[2] = {R, tprev};
+        for (int it = 0; it < n_iter; ++it) {
+            float *cur = raw[it & 1], *prev = raw[(it + 1) & 1];
+            rc = ap_istft_f32(rebuilt, B, T, n_fft, hop, window, tw, frames_ws, out_offset, y_len, y, stream);
+            if (rc != AP_OK) return rc;
+            rc = ap_stft_f32(y, B, y_len, n_fft, hop, window, tw, center, pad_mode, TR, cur, stream);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(ap_gl_project2_kernel, dim3(ap_grid_1d(B * F * T, AP_BLOCK, kApStreamGrid)),
+                               dim3(AP_BLOCK), 0, (hipStream_t)stream, S, reinterpret_cast<const ap_float2 *>(cur),
+                               reinterpret_cast<const ap_float2 *>(prev), B * F * T, momentum,
+                               reinterpret_cast<ap_float2 *>(rebuilt));
+            rc = ap_check_launch("ap_griffinlim_f32(project)");
+            if (rc != AP_OK) return rc;
+        }
+        return ap_istft_f32(rebuilt, B, T, n_fft, hop, window, tw, frames_ws, out_offset, y_len, y, stream);
+    }
     for (int it = 0; it < n_iter; ++it) {
         rc = ap_istft_f32(rebuilt, B, T, n_fft, hop, window, tw, frames_ws, out_offset, y_len, y, stream);
         if (rc != AP_OK) return rc;

@@ -38,6 +38,35 @@ ap_gl_project_kernel(int mode, const float *S, const float *angles, const ap_flo
     }
 }
 
+// mode 1 without the tprev array: tprev = S exp(i angle(R_prev)) is a function of the previous raw
+// STFT, so the loop keeps two raw buffers (ping-pong) and this pass reads R_cur, R_prev and S and
+// writes only `rebuilt` (28 instead of 36 bytes per element).  exp(i angle(R)) = R / |R| (1 for
+// R = 0, like atan2(0, 0) = 0).  Needs TR == T.
+AP_DEV ap_float2 ap_unit_phase(ap_float2 r) {
+    const float n2 = r.x * r.x + r.y * r.y;
+    if (!(n2 > 0.0f)) return ap_mk(1.0f, 0.0f);
+    const float inv = 1.0f / sqrtf(n2);
+    return ap_mk(r.x * inv, r.y * inv);
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_gl_project2_kernel(const float *S, const ap_float2 *Rcur, const ap_float2 *Rprev, int64_t total,
+                      float momentum, ap_float2 *rebuilt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const float s = S[e];
+        const ap_float2 u = ap_unit_phase(Rcur[e]);
+        const ap_float2 rn = ap_mk(s * u.x, s * u.y);
+        if (momentum > 0.0f) {
+            const ap_float2 v = ap_unit_phase(Rprev[e]);
+            const ap_float2 tp = ap_mk(s * v.x, s * v.y);
+            rebuilt[e] = ap_mk(rn.x + momentum * (rn.x - tp.x), rn.y + momentum * (rn.y - tp.y));
+        } else {
+            rebuilt[e] = rn;
+        }
+    }
+}
+
 // order-preserving float <-> uint key so a float max can use an integer atomic
 AP_DEV unsigned ap_fkey(float f) {
     const unsigned u = __builtin_bit_cast(unsigned, f);
