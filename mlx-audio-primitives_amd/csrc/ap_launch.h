@@ -252,7 +252,7 @@ static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels,
     else return false;
     const int nc = n_fft / 2;
     *G = g;
-    int bytes = (2 * g * ap_ct_fs(n_fft) + n_fft + nc) * (int)sizeof(ap_float2);
+    int bytes = (2 * g * ap_ct_fs(n_fft) + n_fft) * (int)sizeof(ap_float2);
     // mel plan tables + partial sums [n_parts][G] + rowstart
     bytes += n_quads * 16 + n_parts * 16 + n_parts * g * 4 + (n_parts > 0 ? (n_mels + 1) * 4 : 0) + 64;
     *lds_bytes = bytes;

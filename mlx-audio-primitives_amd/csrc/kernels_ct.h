@@ -59,15 +59,13 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
     ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
     ap_float2 *bufB = bufA + G * FS;
     ap_float2 *twl = bufB + G * FS;                    // [N] (cos, sin)(2 pi j / N)
-    ap_float2 *winl = twl + N;                         // [NC] window pairs
     // mel plan tables (EPI 1 with a parts plan): weight quads, part descriptors, partial sums, row slots
-    ap_float4 *wql = reinterpret_cast<ap_float4 *>(winl + NC);
+    ap_float4 *wql = reinterpret_cast<ap_float4 *>(twl + N);
     ap_int4 *partl = reinterpret_cast<ap_int4 *>(wql + P.n_quads);
     float *partial = reinterpret_cast<float *>(partl + P.n_parts);            // [n_parts][G]
     int *rsl = reinterpret_cast<int *>(partial + P.n_parts * G);              // [M+1]
     const int tid = threadIdx.x;
     for (int i = tid; i < N; i += AP_BLOCK) twl[i] = P.tw[i];
-    for (int i = tid; i < NC; i += AP_BLOCK) winl[i] = reinterpret_cast<const ap_float2 *>(P.window)[i];
     if (EPI == 1 && P.n_parts > 0) {
         for (int i = tid; i < P.n_quads; i += AP_BLOCK) wql[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
         for (int i = tid; i < P.n_parts; i += AP_BLOCK) partl[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
@@ -76,23 +74,31 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
     AP_LDS_BARRIER();
 
     const int64_t n_tiles = P.tiles_per_clip * P.n_clips;
-    // the samples of a tile are fetched one tile ahead into registers (NI pairs per thread), so
-    // the HBM latency of tile i+1 hides behind the transform of tile i
-    constexpr int NI = (G * NC + AP_BLOCK - 1) / AP_BLOCK;
-    ap_float2 raw[NI];
+    // The first Stockham pass runs straight from registers: thread (g1, j1) owns butterfly j1 of
+    // frame g1 of every tile, so it fetches exactly the R0 sample pairs c = j1 + i PER0 that
+    // butterfly needs (one tile ahead: the HBM latency of tile i+1 hides behind the transform of
+    // tile i) and keeps their window values in registers for the whole kernel.  No window table,
+    // no windowed copy of the tile in LDS, one barrier less.
+    constexpr int PER0 = NC / R0;
+    static_assert(G * PER0 <= AP_BLOCK, "one first-pass butterfly per thread");
+    const bool p1 = tid < G * PER0;
+    const int g1 = tid / PER0, j1 = tid - g1 * PER0;
+    ap_float2 wreg[R0], raw[R0];
+#pragma unroll
+    for (int i = 0; i < R0; ++i)
+        wreg[i] = p1 ? reinterpret_cast<const ap_float2 *>(P.window)[j1 + i * PER0] : ap_mk(0.0f, 0.0f);
     auto load_tile = [&](int64_t tile) {
         const int64_t b = tile / P.tiles_per_clip;
         const int64_t t0 = (tile - b * P.tiles_per_clip) * G;
         const float *yb = P.y + b * P.L;
         const ApClip clip = ap_clip_make(yb, P.L);
+        const bool live = p1 && t0 + g1 < P.T;
+        const int64_t base = (t0 + g1) * (int64_t)P.hop - P.pad;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int item = tid + i * AP_BLOCK;
-            const int g = item / NC;
-            const int c = item - g * NC;
+        for (int i = 0; i < R0; ++i) {
+            const int64_t p = base + 2 * (j1 + i * PER0);
             raw[i] = ap_mk(0.0f, 0.0f);
-            if (item < G * NC && t0 + g < P.T) {
-                const int64_t p = (t0 + g) * (int64_t)P.hop - P.pad + 2 * c;
+            if (live) {
                 if (PADGEN)
                     raw[i] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
                 else
@@ -107,26 +113,25 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
         const int64_t t0 = (tile - b * P.tiles_per_clip) * G;
         const int Gt = (int)((P.T - t0) < G ? (P.T - t0) : G);
 
-        // ---- window + pack as complex into LDS; then put the next tile's loads in flight ----
+        // ---- window, first pass (NS = 1: no twiddles) in registers -> bufB ----------------------
+        {
+            ap_float2 v[R0];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int item = tid + i * AP_BLOCK;
-            if (item < G * NC) {
-                const int g = item / NC;
-                const int c = item - g * NC;
-                const ap_float2 w = winl[c];
-                bufA[g * FS + ap_ct_pad<SH>(c)] = ap_mul2(w, raw[i]);
+            for (int i = 0; i < R0; ++i) v[i] = ap_mul2(wreg[i], raw[i]);
+#ifndef AP_HOST_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);
+#ifndef AP_HOST_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            ApButterfly<R0>::run(v);
+            if (p1) {
+                ap_float2 *dst = bufB + g1 * FS;
+#pragma unroll
+                for (int q = 0; q < R0; ++q) dst[ap_ct_pad<SH>(j1 * R0 + q)] = v[q];
             }
         }
-#ifndef AP_HOST_EMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (tile + gridDim.x < n_tiles) load_tile(tile + gridDim.x);
-#ifndef AP_HOST_EMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        AP_LDS_BARRIER();
-        ap_stockham_pass_ct<R0, NC, 1, G, SH, FS>(bufA, bufB, twl, tid);
         AP_LDS_BARRIER();
         ap_stockham_pass_ct<R1, NC, R0, G, SH, FS>(bufB, bufA, twl, tid);
         AP_LDS_BARRIER();
