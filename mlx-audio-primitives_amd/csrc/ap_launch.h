@@ -231,16 +231,16 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
 }
 
 // compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
-// LDS geometry of the compile-time engine (shared with kernels_ct.h).  A frame's complex slot
-// idx lives at idx + (idx >> sh), sh = log2(first radix): the Stockham pass that writes with
-// stride R0 then hits R0 + 1 apart (conflict-free ds_write_b64); the frame stride FS and the
-// |X|^p plane stride PS are = 4 (mod 32) so that the 8 frames x 4 bins a half-wave touches in
-// the split / power / contraction steps fall into different banks.
-static inline int ap_ct_pad_shift(int n_fft) { return n_fft == 400 ? 3 : 4; }
+// LDS geometry of the compile-time engine (shared with kernels_ct.h).  The first pass (radix R0)
+// leaves its output transposed with the odd row stride PQ = (nc / R0) | 1, so a frame needs
+// max(R0 PQ, nc + 1) complex slots; the frame stride FS and the |X|^p plane stride PS are = 4
+// (mod 32) so that the 8 frames x 4 bins a half-wave touches in the split / power / contraction
+// steps fall into different banks.
 static inline int ap_ct_round4mod32(int v) { return ((v + 27) / 32) * 32 + 4; }
 static inline int ap_ct_fs(int n_fft) {
-    const int nc = n_fft / 2;
-    return ap_ct_round4mod32(nc + (nc >> ap_ct_pad_shift(n_fft)) + 1);
+    const int nc = n_fft / 2, r0 = n_fft == 400 ? 8 : 16;
+    const int pq = (nc / r0) | 1;
+    return ap_ct_round4mod32(r0 * pq > nc + 1 ? r0 * pq : nc + 1);
 }
 static inline int ap_ct_ps(int n_fft) { return ap_ct_round4mod32(n_fft / 2 + 1 + 3); }
 

@@ -64,6 +64,8 @@ AP_PK3(ap_fma_sub_swap, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1
 AP_DEV ap_float2 ap_mul_fw(ap_float2 a, ap_float2 w) { return ap_cmul_tail_fw(a, w, a * w.xx); }
 // a * (c + i s)
 AP_DEV ap_float2 ap_mul_bw(ap_float2 a, ap_float2 w) { return ap_cmul_tail_bw(a, w, a * w.xx); }
+// (c1, s1) (c2, s2) -> (cos, sin) of the summed angle: the product of two table-form twiddles
+AP_DEV ap_float2 ap_cmul(ap_float2 a, ap_float2 b) { return ap_mul_bw(a, b); }
 // compile-time twiddle: the compiler keeps (c, c) and (s, -s) as scalar register pairs
 AP_DEV ap_float2 ap_mul_fw_c(ap_float2 a, float c, float s) {
     return __builtin_elementwise_fma(a.yx, ap_mk(s, -s), a * ap_mk(c, c));
@@ -94,6 +96,7 @@ AP_DEV ap_float2 ap_mul_fw(ap_float2 a, ap_float2 w) {
 AP_DEV ap_float2 ap_mul_bw(ap_float2 a, ap_float2 w) {
     return ap_mk(a.x * w.x - a.y * w.y, a.y * w.x + a.x * w.y);
 }
+AP_DEV ap_float2 ap_cmul(ap_float2 a, ap_float2 b) { return ap_mul_bw(a, b); }
 AP_DEV ap_float2 ap_mul_fw_c(ap_float2 a, float c, float s) { return ap_mul_fw(a, ap_mk(c, s)); }
 AP_DEV ap_float2 ap_mul_bw_c(ap_float2 a, float c, float s) { return ap_mul_bw(a, ap_mk(c, s)); }
 #endif

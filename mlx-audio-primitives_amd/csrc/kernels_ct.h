@@ -8,11 +8,18 @@
 #include "kernels_generic.h"
 #include "kernels_wave.h"     // ApClip / ap_clip_load / ap_float4
 
-// padded slot of complex index idx inside a frame (ap_launch.h: ap_ct_pad_shift)
-template <int SH>
-AP_DEV constexpr int ap_ct_pad(int idx) { return idx + (idx >> SH); }
+// LDS layouts of a frame (ap_launch.h: ap_ct_fs).  The register-resident first pass writes its
+// outputs TRANSPOSED: element idx = R0 j + q sits at q PQ + j, PQ = (NC / R0) | 1, so the R0
+// stores of a thread hit consecutive lanes' slots (conflict-free) instead of a stride-R0 comb,
+// and the second pass, which reads consecutive idx, walks it with the odd stride PQ
+// (conflict-free as well).  Every later buffer is in natural order.
+template <int TR0, int PQ>
+AP_DEV constexpr int ap_ct_slot(int idx) { return TR0 > 0 ? (idx % TR0) * PQ + idx / TR0 : idx; }
 
-template <int R, int NC, int NS, int G, int SH, int FS>
+// TR0 > 0: the source buffer is the transposed first-pass output of radix TR0.
+// Twiddles W^(k i), i = 1..R-1, come from ONE table read (W^k) and powers of it: the engine is
+// LDS-bound and the table reads of a radix-5 pass were as many as its data reads.
+template <int R, int NC, int NS, int G, int FS, int TR0, int PQ>
 AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_float2 *twl, int tid) {
     constexpr int PER = NC / R;
     constexpr int TMUL = (NC / (NS * R)) * 2;          // W_{NS*R}^1 in the W_n table (n = 2 NC)
@@ -24,24 +31,26 @@ AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_fl
         const int k = j % NS;
         ap_float2 v[R];
 #pragma unroll
-        for (int i = 0; i < R; ++i) v[i] = src[ap_ct_pad<SH>(j + i * PER)];
+        for (int i = 0; i < R; ++i) v[i] = src[ap_ct_slot<TR0, PQ>(j + i * PER)];
         if (NS > 1) {
-            const int tk = TMUL * k;
+            ap_float2 w[R];
+            w[1] = twl[TMUL * k];
 #pragma unroll
-            for (int i = 1; i < R; ++i) v[i] = ap_mul_fw(v[i], twl[tk * i]);
+            for (int i = 2; i < R; ++i) w[i] = (i & 1) ? ap_cmul(w[i - 1], w[1]) : ap_cmul(w[i / 2], w[i / 2]);
+#pragma unroll
+            for (int i = 1; i < R; ++i) v[i] = ap_mul_fw(v[i], w[i]);
         }
         ApButterfly<R>::run(v);
         const int j0 = (j / NS) * NS * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) dst[ap_ct_pad<SH>(j0 + q * NS)] = v[q];
+        for (int q = 0; q < R; ++q) dst[j0 + q * NS] = v[q];
     }
 }
 
-// ap_rfft_split (fft_lds.h) on a padded frame
-template <int SH>
+// ap_rfft_split (fft_lds.h) with packed arithmetic
 AP_DEV ap_float2 ap_rfft_split_ct(const ap_float2 *Z, int nc, int k, const ap_float2 *tw) {
-    const ap_float2 zk = Z[ap_ct_pad<SH>(k == nc ? 0 : k)];
-    const ap_float2 zm = Z[ap_ct_pad<SH>(k == 0 ? 0 : nc - k)];
+    const ap_float2 zk = Z[k == nc ? 0 : k];
+    const ap_float2 zm = Z[k == 0 ? 0 : nc - k];
     const ap_float2 a = ap_add_conj(zk, zm), d = ap_sub_conj(zk, zm);
     const ap_float2 w = tw[k];   // (cos, sin)(2 pi k / n)
     // X[k] = a/2 - (i/2) W^k d
@@ -54,8 +63,10 @@ template <int EPI, int NC, int R0, int R1, int R2, int G, int PADGEN>
 __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
     constexpr int N = 2 * NC;
     constexpr int F = NC + 1;
-    constexpr int SH = N == 400 ? 3 : 4;                               // = ap_ct_pad_shift(N)
-    constexpr int FS = ((NC + (NC >> SH) + 1 + 27) / 32) * 32 + 4;     // = ap_ct_fs(N)
+    constexpr int PER0 = NC / R0;
+    constexpr int PQ = PER0 | 1;                                        // odd row stride of the transposed buffer
+    constexpr int FSMIN = R0 * PQ > NC + 1 ? R0 * PQ : NC + 1;
+    constexpr int FS = ((FSMIN + 27) / 32) * 32 + 4;                    // = ap_ct_fs(N, R0)
     ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
     ap_float2 *bufB = bufA + G * FS;
     ap_float2 *twl = bufB + G * FS;                    // [N] (cos, sin)(2 pi j / N)
@@ -79,7 +90,6 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
     // butterfly needs (one tile ahead: the HBM latency of tile i+1 hides behind the transform of
     // tile i) and keeps their window values in registers for the whole kernel.  No window table,
     // no windowed copy of the tile in LDS, one barrier less.
-    constexpr int PER0 = NC / R0;
     static_assert(G * PER0 <= AP_BLOCK, "one first-pass butterfly per thread");
     const bool p1 = tid < G * PER0;
     const int g1 = tid / PER0, j1 = tid - g1 * PER0;
@@ -129,16 +139,16 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             if (p1) {
                 ap_float2 *dst = bufB + g1 * FS;
 #pragma unroll
-                for (int q = 0; q < R0; ++q) dst[ap_ct_pad<SH>(j1 * R0 + q)] = v[q];
+                for (int q = 0; q < R0; ++q) dst[q * PQ + j1] = v[q];
             }
         }
         AP_LDS_BARRIER();
-        ap_stockham_pass_ct<R1, NC, R0, G, SH, FS>(bufB, bufA, twl, tid);
+        ap_stockham_pass_ct<R1, NC, R0, G, FS, R0, PQ>(bufB, bufA, twl, tid);
         AP_LDS_BARRIER();
         ap_float2 *Z = bufA;
         ap_float2 *other = bufB;
         if (R2 > 1) {
-            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G, SH, FS>(bufA, bufB, twl, tid);
+            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G, FS, 0, 1>(bufA, bufB, twl, tid);
             AP_LDS_BARRIER();
             Z = bufB;
             other = bufA;
@@ -148,7 +158,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             for (int item = tid; item < F * G; item += AP_BLOCK) {
                 const int k = item / G;
                 const int g = item - k * G;
-                if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split_ct<SH>(Z + g * FS, NC, k, twl);
+                if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split_ct(Z + g * FS, NC, k, twl);
             }
             AP_LDS_BARRIER();
         } else {
@@ -158,7 +168,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             for (int item = tid; item < F * G; item += AP_BLOCK) {
                 const int k = item / G;
                 const int g = item - k * G;
-                const ap_float2 X = ap_rfft_split_ct<SH>(Z + g * FS, NC, k, twl);
+                const ap_float2 X = ap_rfft_split_ct(Z + g * FS, NC, k, twl);
                 Pw[g * PS + k] = ap_pow_mag(X.x, X.y, P.power);
             }
             if (P.n_parts > 0) {

@@ -104,10 +104,12 @@ def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, bande
     out = np.zeros((B, M, T), np.float32)
     window = np.ascontiguousarray(window, np.float32)
     tw = twiddles(n_fft)
-    if banded:
+    if banded or force_generic:
         plan, desc = mel_plan(fb)
+        if not banded:
+            desc[0] = 0                      # dense contraction (no band spans, no parts)
         if force_generic:
-            desc[0] |= 256
+            desc[0] |= 256                   # AP_PLAN_FORCE_GENERIC: keep the generic LDS engine
         plan_p, desc_p = plan.ctypes.data_as(_i32p), desc.ctypes.data_as(_i32p)
     else:
         plan_p = desc_p = None

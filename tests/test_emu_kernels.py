@@ -60,10 +60,13 @@ def test_emu_melspec(sr, n_fft, hop, M, L, B, power):
     fb = ao.mel_filterbank(sr, n_fft, M)
     R = ao.melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M, power=power)
     banded = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=True, force_generic=True)
-    dense = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=False)
+    dense = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=False, force_generic=True)
     np.testing.assert_allclose(banded, R, rtol=1e-4, atol=1e-4)
-    # skipping the zeros outside each filter's span must not change a single bit
+    # skipping the zeros outside each filter's span must not change a single bit (same engine)
     np.testing.assert_array_equal(banded, dense)
+    # no plan at all: dense contraction on whichever engine serves this n_fft
+    np.testing.assert_allclose(eb.melspec(y, n_fft, hop, win, fb, power=power, banded=False), R,
+                               rtol=1e-4, atol=1e-4)
     # with the plan: n_fft=2048 -> wave kernel, 400/512/1024 -> compile-time engine with the
     # LDS parts contraction
     planned = eb.melspec(y, n_fft, hop, win, fb, power=power, banded=True)
