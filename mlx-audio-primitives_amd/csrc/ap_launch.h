@@ -250,7 +250,6 @@ static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels,
     else if (n_fft == 512) g = 8;
     else if (n_fft == 1024) g = 8;
     else return false;
-    const int nc = n_fft / 2;
     *G = g;
     int bytes = (2 * g * ap_ct_fs(n_fft) + n_fft) * (int)sizeof(ap_float2);
     // mel plan tables + partial sums [n_parts][G] + rowstart

@@ -492,7 +492,6 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
     for (int64_t group = g_lo; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;
         const int64_t t0 = (group - b * P.groups_per_clip) * APS_WAVES;
-        const int Gt = (int)((P.T - t0) < APS_WAVES ? (P.T - t0) : APS_WAVES);
         ap_float2 *ob = P.out + b * (int64_t)F * P.T + t0;
         if (PADGEN) load_frame(group);
         // (complex index of out[b, 0, t0]) mod 8: the same for every group of a clip

@@ -5,6 +5,7 @@ the evidence table for DESIGN.md / profiles/README.md.
   cfg2  batch=256 x 10 s @16 kHz   melspectrogram n_fft=400 hop=160 n_mels=80 (Whisper)
   cfg3  batch=64 x 5 s @22.05 kHz  stft -> istft round trip, and griffinlim(32 iterations)
   cfg4  batch=1024 x 10 s @48 kHz  resample_poly 48k->16k, then mfcc(n_mfcc=13)
+  cfg5  batch=4096 x 30 s @16 kHz mel pipeline over 8 GPUs: the per-GPU shard, 512 x 30 s
   head  batch=256 x 10 s @22.05kHz melspectrogram n_fft=2048 hop=512 n_mels=128
 """
 import json
@@ -79,6 +80,15 @@ def main():
     ms_m = timeit(lambda: ap.mfcc(y16, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128),
                   warm=2, reps=5)
     rep["cfg4_mfcc13"] = dict(ms=ms_m, frames_per_s=1024 * 313 / ms_m * 1e3)
+    del y16
+    # cfg5: one GPU's shard of 4096 x 30 s @ 16 kHz (983 MB of samples)
+    y = torch.randn((512, 480000), device="cuda", generator=g) * 0.1
+    ms = timeit(lambda: ap.melspectrogram(y, sr=16000, n_fft=400, hop_length=160, n_mels=80), warm=2, reps=5)
+    rep["cfg5_shard_whisper_mel400"] = dict(ms=ms, frames_per_s=512 * 3001 / ms * 1e3,
+                                            alg_GBps=(4 * 160 + 4 * 80) * 512 * 3001 / ms / 1e6)
+    ms = timeit(lambda: ap.melspectrogram(y, sr=16000, n_fft=2048, hop_length=512, n_mels=128), warm=2, reps=5)
+    rep["cfg5_shard_mel2048"] = dict(ms=ms, frames_per_s=512 * 938 / ms * 1e3,
+                                     alg_GBps=(4 * 512 + 4 * 128) * 512 * 938 / ms / 1e6)
     print(json.dumps(rep, indent=1))
 
 
