@@ -197,6 +197,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.quads = reinterpret_cast<const float *>(plan + desc[13]);
     W.n_quads = desc[14];
     W.n_slots = desc[7];
+    W.hopj = (P.hop == 256 || P.hop == 512 || P.hop == 1024) ? P.hop / 128 : 0;
     W.max_row_parts = desc[15];
     W.partial_stride = (W.n_slots + 1 + 3 + 3) & ~3;
     W.rowstart = plan + desc[10];

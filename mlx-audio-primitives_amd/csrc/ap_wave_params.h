@@ -23,6 +23,7 @@ struct ApMelWaveParams {
     float *out;                // (B, M, T)
     int64_t L, T, tiles_per_clip, n_tiles, n_clips;
     int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots;   // n_slots: partial sums per frame
+    int hopj;                  // hop / 128 when the next frame reuses this one's registers (2, 4, 8), else 0
     int max_row_parts;         // largest number of parts of one row
     int partial_stride;        // floats between the waves' partial-sum arrays (n_slots + dump slot + 3 read-ahead)
     float power;

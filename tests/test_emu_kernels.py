@@ -80,7 +80,7 @@ def test_emu_melspec(sr, n_fft, hop, M, L, B, power):
     (22050, 128, 17 * 512, 1, 1.5, "constant", dict(norm=None)),
 ])
 def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
-    """kernels_wave.h (n_fft=2048, wave per frame, DPP quad radix-4, LDS atomics) on the CPU."""
+    """kernels_wave.h (n_fft=2048, wave per frame, DPP quad radix-4, plan contraction) on the CPU."""
     rng = np.random.default_rng(L)
     y = rng.standard_normal((B, L)).astype(np.float32)
     win = ao.padded_window("hann", 2048, 2048)
@@ -90,6 +90,19 @@ def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
     A = eb.melspec(y, 2048, 512, win, fb, power=power, pad_mode=PM[pad_mode])
     R = ao.melspectrogram(y, sr=sr, n_fft=2048, hop_length=512, n_mels=M, power=power,
                           pad_mode=pad_mode, **kw)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("hop", [256, 1024, 500, 128])
+def test_emu_wave_kernel_hops(hop):
+    """Frame-to-frame register reuse of the overlapping samples (hop 256 / 512 / 1024) against the
+    full-frame loads every other hop takes; two clips so a clip change falls inside a stretch."""
+    rng = np.random.default_rng(hop)
+    y = rng.standard_normal((2, 7000)).astype(np.float32)
+    win = ao.padded_window("hann", 2048, 2048)
+    fb = ao.mel_filterbank(22050, 2048, 64)
+    A = eb.melspec(y, 2048, hop, win, fb)
+    R = ao.melspectrogram(y, sr=22050, n_fft=2048, hop_length=hop, n_mels=64)
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
 
 
