@@ -58,6 +58,20 @@ AP_DEV ap_float2 ap_rfft_split_ct(const ap_float2 *Z, int nc, int k, const ap_fl
     return ap_fma_add_mi(a, ap_mk(0.5f, 0.5f), u);
 }
 
+// Both bins of a mirrored pair from one pair of reads (k in [0, nc/2]): X[k] and conj X[nc-k]
+//   a = Z[k] + conj Z[nc-k], d = Z[k] - conj Z[nc-k], u = (W^k / 2) d
+//   X[k] = a/2 + (-i) u,  conj X[nc-k] = a/2 - (-i) u          (k = 0: X[0] and X[nc])
+AP_DEV void ap_rfft_split_pair_ct(const ap_float2 *Z, int nc, int k, const ap_float2 *tw, ap_float2 &xk,
+                                  ap_float2 &xm_conj) {
+    const ap_float2 zk = Z[k];
+    const ap_float2 zm = Z[k == 0 ? 0 : nc - k];
+    const ap_float2 a = ap_add_conj(zk, zm), d = ap_sub_conj(zk, zm);
+    const ap_float2 u = ap_mul_fw(d, ap_scale(tw[k], 0.5f));
+    const ap_float2 h = ap_mk(0.5f, 0.5f);
+    xk = ap_fma_add_mi(a, h, u);
+    xm_conj = ap_fma_sub_mi(a, h, u);
+}
+
 // EPI 0: complex (B,F,T); EPI 1: mel (B,M,T).  R2 = 1: two passes only.
 template <int EPI, int NC, int R0, int R1, int R2, int G, int PADGEN>
 __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
@@ -155,21 +169,28 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
         }
 
         if (EPI == 0) {
-            for (int item = tid; item < F * G; item += AP_BLOCK) {
+            for (int item = tid; item < (NC / 2 + 1) * G; item += AP_BLOCK) {
                 const int k = item / G;
                 const int g = item - k * G;
-                if (g < Gt) P.out_c[(b * F + k) * P.T + t0 + g] = ap_rfft_split_ct(Z + g * FS, NC, k, twl);
+                ap_float2 xk, xm;
+                ap_rfft_split_pair_ct(Z + g * FS, NC, k, twl, xk, xm);
+                if (g < Gt) {
+                    P.out_c[(b * F + k) * P.T + t0 + g] = xk;
+                    if (2 * k != NC) P.out_c[(b * F + (NC - k)) * P.T + t0 + g] = ap_mk(xm.x, -xm.y);
+                }
             }
             AP_LDS_BARRIER();
         } else {
             float *Pw = reinterpret_cast<float *>(other);
             constexpr int PS = ((F + 3 + 27) / 32) * 32 + 4;   // = ap_ct_ps(N): 16-byte aligned planes, >= F + 3
             static_assert(PS <= 2 * FS, "power planes alias the idle exchange buffer");
-            for (int item = tid; item < F * G; item += AP_BLOCK) {
+            for (int item = tid; item < (NC / 2 + 1) * G; item += AP_BLOCK) {
                 const int k = item / G;
                 const int g = item - k * G;
-                const ap_float2 X = ap_rfft_split_ct(Z + g * FS, NC, k, twl);
-                Pw[g * PS + k] = ap_pow_mag(X.x, X.y, P.power);
+                ap_float2 xk, xm;
+                ap_rfft_split_pair_ct(Z + g * FS, NC, k, twl, xk, xm);     // |conj X| = |X|
+                Pw[g * PS + k] = ap_pow_mag(xk.x, xk.y, P.power);
+                if (2 * k != NC) Pw[g * PS + NC - k] = ap_pow_mag(xm.x, xm.y, P.power);
             }
             if (P.n_parts > 0) {
                 // zero the alignment tail of every plane: the last weight quad may reach past bin F-1
