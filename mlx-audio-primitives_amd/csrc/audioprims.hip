@@ -57,16 +57,16 @@ static int ap_launch_ct(ApStftParams &P, int n_fft, int64_t B, void *stream, boo
     const int per_cu = AP_LDS_MAX / lds < 8 ? AP_LDS_MAX / lds : 8;
     int64_t grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
     int rc = AP_OK;
-#define AP_CT_LAUNCH(NC, R0, R1, R2, GG)                                                             \
-    do {                                                                                             \
-        rc = ap_allow_lds(ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN>, lds);                  \
-        if (rc != AP_OK) return rc;                                                                  \
-        hipLaunchKernelGGL((ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN>), dim3((unsigned)grid), \
-                           dim3(AP_BLOCK), lds, (hipStream_t)stream, P);                             \
+#define AP_CT_LAUNCH(NC, R0, R1, R2, GG, NT)                                                             \
+    do {                                                                                                 \
+        rc = ap_allow_lds(ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN, NT>, lds);                  \
+        if (rc != AP_OK) return rc;                                                                      \
+        hipLaunchKernelGGL((ap_stft_ct_kernel<EPI, NC, R0, R1, R2, GG, PADGEN, NT>), dim3((unsigned)grid), \
+                           dim3(NT), lds, (hipStream_t)stream, P);                                       \
     } while (0)
-    if (n_fft == 400) AP_CT_LAUNCH(200, 8, 5, 5, 8);
-    else if (n_fft == 512) AP_CT_LAUNCH(256, 16, 16, 1, 8);
-    else AP_CT_LAUNCH(512, 16, 8, 4, 8);
+    if (n_fft == 400) AP_CT_LAUNCH(200, 8, 5, 5, 8, 256);
+    else if (n_fft == 512) AP_CT_LAUNCH(256, 16, 16, 1, 8, 256);
+    else AP_CT_LAUNCH(512, 16, 8, 4, 8, 256);
 #undef AP_CT_LAUNCH
     *handled = true;
     return ap_check_launch("ap_stft_ct");

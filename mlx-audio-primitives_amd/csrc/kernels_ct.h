@@ -19,11 +19,11 @@ AP_DEV constexpr int ap_ct_slot(int idx) { return TR0 > 0 ? (idx % TR0) * PQ + i
 // TR0 > 0: the source buffer is the transposed first-pass output of radix TR0.
 // Twiddles W^(k i), i = 1..R-1, come from ONE table read (W^k) and powers of it: the engine is
 // LDS-bound and the table reads of a radix-5 pass were as many as its data reads.
-template <int R, int NC, int NS, int G, int FS, int TR0, int PQ>
+template <int R, int NC, int NS, int G, int FS, int TR0, int PQ, int NT>
 AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_float2 *twl, int tid) {
     constexpr int PER = NC / R;
     constexpr int TMUL = (NC / (NS * R)) * 2;          // W_{NS*R}^1 in the W_n table (n = 2 NC)
-    for (int item = tid; item < G * PER; item += AP_BLOCK) {
+    for (int item = tid; item < G * PER; item += NT) {
         const int g = item / PER;
         const int j = item - g * PER;
         const ap_float2 *src = in + g * FS;
@@ -73,8 +73,11 @@ AP_DEV void ap_rfft_split_pair_ct(const ap_float2 *Z, int nc, int k, const ap_fl
 }
 
 // EPI 0: complex (B,F,T); EPI 1: mel (B,M,T).  R2 = 1: two passes only.
-template <int EPI, int NC, int R0, int R1, int R2, int G, int PADGEN>
-__global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
+// NT threads per workgroup (256 everywhere: 320 for the 8.5.5 plan, whose radix-5 passes have
+// 8 x 40 = 320 butterflies per tile, measured slower - 0.31 against 0.20 ms - five waves do not
+// spread over four SIMDs).
+template <int EPI, int NC, int R0, int R1, int R2, int G, int PADGEN, int NT>
+__global__ void __launch_bounds__(NT) ap_stft_ct_kernel(ApStftParams P) {
     constexpr int N = 2 * NC;
     constexpr int F = NC + 1;
     constexpr int PER0 = NC / R0;
@@ -90,11 +93,11 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
     float *partial = reinterpret_cast<float *>(partl + P.n_parts);            // [n_parts][G]
     int *rsl = reinterpret_cast<int *>(partial + P.n_parts * G);              // [M+1]
     const int tid = threadIdx.x;
-    for (int i = tid; i < N; i += AP_BLOCK) twl[i] = P.tw[i];
+    for (int i = tid; i < N; i += NT) twl[i] = P.tw[i];
     if (EPI == 1 && P.n_parts > 0) {
-        for (int i = tid; i < P.n_quads; i += AP_BLOCK) wql[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
-        for (int i = tid; i < P.n_parts; i += AP_BLOCK) partl[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
-        for (int i = tid; i <= P.n_mels; i += AP_BLOCK) rsl[i] = P.rowstart[i];
+        for (int i = tid; i < P.n_quads; i += NT) wql[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
+        for (int i = tid; i < P.n_parts; i += NT) partl[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
+        for (int i = tid; i <= P.n_mels; i += NT) rsl[i] = P.rowstart[i];
     }
     AP_LDS_BARRIER();
 
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
     // butterfly needs (one tile ahead: the HBM latency of tile i+1 hides behind the transform of
     // tile i) and keeps their window values in registers for the whole kernel.  No window table,
     // no windowed copy of the tile in LDS, one barrier less.
-    static_assert(G * PER0 <= AP_BLOCK, "one first-pass butterfly per thread");
+    static_assert(G * PER0 <= NT, "one first-pass butterfly per thread");
     const bool p1 = tid < G * PER0;
     const int g1 = tid / PER0, j1 = tid - g1 * PER0;
     ap_float2 wreg[R0], raw[R0];
@@ -157,19 +160,19 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             }
         }
         AP_LDS_BARRIER();
-        ap_stockham_pass_ct<R1, NC, R0, G, FS, R0, PQ>(bufB, bufA, twl, tid);
+        ap_stockham_pass_ct<R1, NC, R0, G, FS, R0, PQ, NT>(bufB, bufA, twl, tid);
         AP_LDS_BARRIER();
         ap_float2 *Z = bufA;
         ap_float2 *other = bufB;
         if (R2 > 1) {
-            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G, FS, 0, 1>(bufA, bufB, twl, tid);
+            ap_stockham_pass_ct<(R2 > 1 ? R2 : 2), NC, R0 * R1, G, FS, 0, 1, NT>(bufA, bufB, twl, tid);
             AP_LDS_BARRIER();
             Z = bufB;
             other = bufA;
         }
 
         if (EPI == 0) {
-            for (int item = tid; item < (NC / 2 + 1) * G; item += AP_BLOCK) {
+            for (int item = tid; item < (NC / 2 + 1) * G; item += NT) {
                 const int k = item / G;
                 const int g = item - k * G;
                 ap_float2 xk, xm;
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             float *Pw = reinterpret_cast<float *>(other);
             constexpr int PS = ((F + 3 + 27) / 32) * 32 + 4;   // = ap_ct_ps(N): 16-byte aligned planes, >= F + 3
             static_assert(PS <= 2 * FS, "power planes alias the idle exchange buffer");
-            for (int item = tid; item < (NC / 2 + 1) * G; item += AP_BLOCK) {
+            for (int item = tid; item < (NC / 2 + 1) * G; item += NT) {
                 const int k = item / G;
                 const int g = item - k * G;
                 ap_float2 xk, xm;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             }
             if (P.n_parts > 0) {
                 // zero the alignment tail of every plane: the last weight quad may reach past bin F-1
-                for (int item = tid; item < 3 * G; item += AP_BLOCK) {
+                for (int item = tid; item < 3 * G; item += NT) {
                     const int g = item / 3, k = F + (item - g * 3);
                     if (k < PS) Pw[g * PS + k] = 0.0f;
                 }
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
             AP_LDS_BARRIER();
             if (P.n_parts > 0) {
                 // plan-based banded contraction, everything from LDS (16-byte reads)
-                for (int item = tid; item < P.n_parts * G; item += AP_BLOCK) {
+                for (int item = tid; item < P.n_parts * G; item += NT) {
                     const int p = item / G;
                     const int g = item - p * G;
                     const ap_int4 pd = partl[p];                       // slot, g0, ng, q0
@@ -219,7 +222,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                     partial[pd.x * G + g] = acc;
                 }
                 AP_LDS_BARRIER();
-                for (int item = tid; item < P.n_mels * G; item += AP_BLOCK) {
+                for (int item = tid; item < P.n_mels * G; item += NT) {
                     const int m = item / G;
                     const int g = item - m * G;
                     if (g < Gt) {
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_ct_kernel(ApStftParams P) {
                     }
                 }
             } else {
-                for (int item = tid; item < P.n_mels * G; item += AP_BLOCK) {
+                for (int item = tid; item < P.n_mels * G; item += NT) {
                     const int m = item / G;
                     const int g = item - m * G;
                     if (g < Gt) {

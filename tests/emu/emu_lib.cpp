@@ -24,9 +24,9 @@ static bool emu_launch_ct(ApStftParams &P, int n_fft, int64_t B) {
     P.tiles_per_clip = (P.T + G - 1) / G;
     int64_t tiles = P.tiles_per_clip * B;
     unsigned grid = (unsigned)(tiles < 3 ? tiles : 3);        // exercise the persistent loop
-    if (n_fft == 400) emu_launch(grid, AP_BLOCK, [&] { ap_stft_ct_kernel<EPI, 200, 8, 5, 5, 8, PADGEN>(P); });
-    else if (n_fft == 512) emu_launch(grid, AP_BLOCK, [&] { ap_stft_ct_kernel<EPI, 256, 16, 16, 1, 8, PADGEN>(P); });
-    else emu_launch(grid, AP_BLOCK, [&] { ap_stft_ct_kernel<EPI, 512, 16, 8, 4, 8, PADGEN>(P); });
+    if (n_fft == 400) emu_launch(grid, 256, [&] { ap_stft_ct_kernel<EPI, 200, 8, 5, 5, 8, PADGEN, 256>(P); });
+    else if (n_fft == 512) emu_launch(grid, 256, [&] { ap_stft_ct_kernel<EPI, 256, 16, 16, 1, 8, PADGEN, 256>(P); });
+    else emu_launch(grid, 256, [&] { ap_stft_ct_kernel<EPI, 512, 16, 8, 4, 8, PADGEN, 256>(P); });
     return true;
 }
 
