@@ -1,5 +1,5 @@
 """Run one operator a few times on the headline-sized batch (for rocprofv3 passes).
-usage: python3 tools/run_op.py {stft|istft|mel|whisper|gl|mfcc} [reps]"""
+usage: python3 tools/run_op.py {stft|istft|mel|whisper|gl|mfcc|resample} [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,9 @@ g = torch.Generator(device="cuda").manual_seed(1)
 if op == "whisper":
     y = torch.randn((256, 160000), device="cuda", generator=g) * 0.1
     fn = lambda: ap.melspectrogram(y, sr=16000, n_fft=400, hop_length=160, n_mels=80)
+elif op == "resample":
+    y = torch.randn((1024, 480000), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.resample_poly(y, 1, 3)
 elif op == "mfcc":
     y = torch.randn((1024, 160000), device="cuda", generator=g) * 0.1
     fn = lambda: ap.mfcc(y, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
