@@ -654,21 +654,23 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
         return (int)(((reinterpret_cast<uintptr_t>(P.S) >> 3) + (uint64_t)(b * (int64_t)F * P.T)) & 7);
     };
     // the window of every row that starts phi(row) + dt0 frames after frame 0 of clip b
-    auto load_window = [&](ap_float2 (&w)[4][4], ap_float2 &wmid, int64_t b, int64_t dt0) {
+    // (32-bit arithmetic: the launch code bounds T by 2^20, so bin T + t < 2^31)
+    auto load_window = [&](ap_float2 (&w)[4][4], ap_float2 &wmid, int64_t b, int dt0) {
         const int a0 = clip_phase(b);
         const ap_float2 *sb = P.S + b * (int64_t)F * P.T;
+        const int tb = dt0 + sf;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 2 * c + (i >> 1);
                 const int bin = (i & 1) ? APW_NC - 64 * r - sq : 64 * r + sq;
-                const int64_t t = dt0 + ((0 - (a0 + bin * T7)) & 7) + sf;
-                w[c][i] = (t >= 0 && t < P.T) ? sb[bin * Ti + (int)t] : ap_mk(0.0f, 0.0f);
+                const int t = tb + ((0 - (a0 + bin * T7)) & 7);
+                w[c][i] = (unsigned)t < (unsigned)Ti ? sb[bin * Ti + t] : ap_mk(0.0f, 0.0f);
             }
         if (tid < APS_WAVES) {
-            const int64_t t = dt0 + ((0 - (a0 + (APW_NC / 2) * T7)) & 7) + sf;
-            wmid = (t >= 0 && t < P.T) ? sb[(APW_NC / 2) * Ti + (int)t] : ap_mk(0.0f, 0.0f);
+            const int t = tb + ((0 - (a0 + (APW_NC / 2) * T7)) & 7);
+            wmid = (unsigned)t < (unsigned)Ti ? sb[(APW_NC / 2) * Ti + t] : ap_mk(0.0f, 0.0f);
         }
     };
     // OLA: a stretch that starts inside a clip begins one group early (stores disabled)
@@ -676,8 +678,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
     if (g_first < g_hi) {
         const int64_t b = g_first / P.groups_per_clip;
         const int64_t t0 = (g_first - b * P.groups_per_clip) * APS_WAVES;
-        load_window(wa, wa_mid, b, t0 - 8);
-        load_window(wb, wb_mid, b, t0);
+        load_window(wa, wa_mid, b, (int)t0 - 8);
+        load_window(wb, wb_mid, b, (int)t0);
     }
     for (int64_t group = g_first; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;
@@ -722,9 +724,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
                     for (int i = 0; i < 4; ++i) wa[c][i] = wb[c][i];
                 wa_mid = wb_mid;
             } else {
-                load_window(wa, wa_mid, bn, tn - 8);
+                load_window(wa, wa_mid, bn, (int)tn - 8);
             }
-            load_window(wb, wb_mid, bn, tn);
+            load_window(wb, wb_mid, bn, (int)tn);
         }
         AP_SCHED_FENCE();
         // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[1024-k]) / 2 of the packed inverse -----
@@ -787,19 +789,24 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
         const bool clip_last = t0 + APS_WAVES >= P.T;
         const float *XF = reinterpret_cast<const float *>(ap_smem);  // frame f at XF + f * 2 APW_X_COMPLEX
         const int n_own = APS_WAVES * H;                             // positions this group completes
+        const int hs = H == 256 ? 8 : (H == 512 ? 9 : 10);           // H = 1 << hs
         const int64_t p0 = t0 * (int64_t)H;                          // padded position of r = 0
+        const int t0i = (int)t0;
         float *yb = P.y + b * P.out_len;
+        const int64_t n0 = p0 - P.out_offset;                        // output index of r = 0
         for (int r = 4 * tid; r < n_own + CN; r += 4 * 64 * APS_WAVES) {
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
             if (r < CN) {
                 const ap_float4 c4 = *reinterpret_cast<const ap_float4 *>(carry_in + r);
                 s0 = c4.x; s1 = c4.y; s2 = c4.z; s3 = c4.w;
             }
-            const int f_lo = r < 2 * APW_NC ? 0 : (r - 2 * APW_NC) / H + 1;
-            int f_hi = r / H;
+            // frames of this group that cover r: f H <= r < f H + n_fft (arithmetic shifts floor)
+            const int f_cov = ((r - 2 * APW_NC) >> hs) + 1;          // first covering frame, may be < 0
+            const int f_lo = f_cov < 0 ? 0 : f_cov;
+            int f_hi = r >> hs;
             if (f_hi > APS_WAVES - 1) f_hi = APS_WAVES - 1;
             for (int f = f_lo; f <= f_hi; ++f) {
-                const int sidx = r - f * H;                          // sample index in frame f (multiple of 4)
+                const int sidx = r - (f << hs);                      // sample index in frame f (multiple of 4)
                 const ap_float4 q = *reinterpret_cast<const ap_float4 *>(
                     XF + f * (2 * APW_X_COMPLEX) + 2 * apw_zidx(sidx >> 1));
                 s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
@@ -809,21 +816,28 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
                 *reinterpret_cast<ap_float4 *>(carry_out + (r - n_own)) = c4;
             }
             if (emit && (r < n_own || clip_last)) {
-                const int64_t p = p0 + r;
-                // window-sum-of-squares over the frames of the clip that cover p
-                int64_t F_lo = p < 2 * APW_NC ? 0 : (p - 2 * APW_NC) / H + 1;
-                int64_t F_hi = p / H;
-                if (F_hi > P.T - 1) F_hi = P.T - 1;
+                // window-sum-of-squares over the frames of the CLIP that cover the position
+                // (relative frame numbers; frames before this group count too)
+                int F_lo = f_cov < -t0i ? -t0i : f_cov;
+                int F_hi = r >> hs;
+                if (F_hi > Ti - 1 - t0i) F_hi = Ti - 1 - t0i;
                 float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, w3 = 0.0f;
-                for (int64_t Fi = F_lo; Fi <= F_hi; ++Fi) {
-                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (int)(p - Fi * H));
+                for (int Fi = F_lo; Fi <= F_hi; ++Fi) {
+                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (r - Fi * H));
                     w0 += w.x * w.x; w1 += w.y * w.y; w2 += w.z * w.z; w3 += w.w * w.w;
                 }
-                const int64_t n = p - P.out_offset;
-                if (n >= 0 && n < P.out_len) yb[n] = s0 / fmaxf(w0, 1e-8f);
-                if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
-                if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
-                if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+                const int64_t n = n0 + r;
+                if (n >= 0 && n + 3 < P.out_len) {
+                    yb[n] = s0 / fmaxf(w0, 1e-8f);
+                    yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
+                    yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
+                    yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+                } else {
+                    if (n >= 0 && n < P.out_len) yb[n] = s0 / fmaxf(w0, 1e-8f);
+                    if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
+                    if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
+                    if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+                }
             }
         }
         if (emit && clip_last) {                                     // no frame reaches beyond the tail: 0 / 1e-8
