@@ -22,6 +22,10 @@ struct __attribute__((aligned(8))) ap_float2 {
 };
 #endif
 
+// 16-byte LDS / global accesses
+struct __attribute__((aligned(16))) ap_float4 { float x, y, z, w; };
+struct __attribute__((aligned(16))) ap_int4 { int x, y, z, w; };
+
 // Radix plan of the complex transform that backs an n_fft-point real transform.
 //   even n_fft : nc = n_fft/2 complex points (pack x[2n] + i x[2n+1]) + split pass
 //   odd  n_fft : nc = n_fft complex points with zero imaginary part

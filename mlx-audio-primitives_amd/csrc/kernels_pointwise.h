@@ -91,7 +91,20 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_reduce_max_kernel(const float *x,
     float *red = reinterpret_cast<float *>(ap_smem);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float m = -INFINITY;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) m = fmaxf(m, x[e]);
+    // 16-byte loads over the aligned body, scalar loads for the unaligned head and the tail
+    const int64_t head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2;
+    const int64_t h = head < n ? head : n;
+    const int64_t nq = (n - h) >> 2;
+    const ap_float4 *xq = reinterpret_cast<const ap_float4 *>(x + h);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nq; e += stride) {
+        const ap_float4 v = xq[e];
+        m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    if (blockIdx.x == 0) {
+        if ((int64_t)threadIdx.x < h) m = fmaxf(m, x[threadIdx.x]);
+        const int64_t t = h + 4 * nq + threadIdx.x;
+        if (t < n) m = fmaxf(m, x[t]);
+    }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {

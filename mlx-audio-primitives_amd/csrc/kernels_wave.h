@@ -53,8 +53,6 @@ AP_DEV float ap_quad_xor2(float x) {   // value of lane ^ 2 (quad_perm [2,3,0,1]
 }
 #endif
 
-struct __attribute__((aligned(16))) ap_float4 { float x, y, z, w; };
-struct __attribute__((aligned(16))) ap_int4 { int x, y, z, w; };
 
 // natural-order index k -> padded LDS slot: conflict-free ds_write_b64 of the quad
 // outputs and (nearly) conflict-free ds_read_b64 of Z[lane+64r] / Z[1024-lane-64r]
