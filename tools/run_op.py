@@ -11,6 +11,12 @@ g = torch.Generator(device="cuda").manual_seed(1)
 if op == "whisper":
     y = torch.randn((256, 160000), device="cuda", generator=g) * 0.1
     fn = lambda: ap.melspectrogram(y, sr=16000, n_fft=400, hop_length=160, n_mels=80)
+elif op == "resfft":
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.resample(y, 22050, 16000, res_type="fft")
+elif op == "reslin":
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.resample(y, 22050, 16000, res_type="linear")
 elif op == "resample":
     y = torch.randn((1024, 480000), device="cuda", generator=g) * 0.1
     fn = lambda: ap.resample_poly(y, 1, 3)
