@@ -15,12 +15,10 @@ AP_DEV void ap_sincos_2pi(double frac, float *s, float *c) {
     *c = (float)cosl(a);
 }
 #else
-AP_DEV void ap_sincos_2pi(double frac, float *s, float *c) {
-    double sd, cd;
-    sincospi(2.0 * frac, &sd, &cd);
-    *s = (float)sd;
-    *c = (float)cd;
-}
+// float32 sincospi of a double-precision turn fraction: the argument is exact to 6e-8 turns
+// (3.7e-7 rad), the evaluation to an ulp - against a float64 sincospi this costs < 1e-6 relative on
+// the twiddle and saves ~100 instructions per element of the twiddled leg
+AP_DEV void ap_sincos_2pi(double frac, float *s, float *c) { sincospif((float)(2.0 * frac), s, c); }
 #endif
 
 __global__ void __launch_bounds__(AP_BLOCK) ap_cfft_strided_kernel(ApCfftParams P) {
@@ -60,7 +58,8 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_cfft_strided_kernel(ApCfftParams 
         if (g < Gt) {
             ap_float2 v = Z[g * fstride + k];
             if (P.tw_N > 0) {
-                const int64_t m = ((f0 + g) * (int64_t)k) % P.tw_N;
+                // n2 k1 < N2 N1 = N: no reduction needed, and the product fits 32 bits (both <= 4096)
+                const unsigned m = (unsigned)(f0 + g) * (unsigned)k;
                 float s, c;
                 ap_sincos_2pi((double)m / (double)P.tw_N, &s, &c);
                 v = ap_mul_fw(v, ap_mk(c, s));              // * exp(-2 pi i m / N)
