@@ -176,6 +176,15 @@ int ap_melspec_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int 
                    const int32_t *plan /*dev*/, const int32_t *desc /*host, 16 ints*/,
                    int n_mels, float power, float *out /*dev (B,M,T)*/, void *stream);
 
+/* The same, and also raises *max_key_dev (order-preserving key as in ap_reduce_max_f32, reset by
+ * the call) to max(out): mfcc's top_db clip needs the global maximum of the mel power, and the
+ * n_fft = 2048 kernel gets it for one atomic per wavefront instead of another pass over out. */
+int ap_melspec_max_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop,
+                       const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
+                       int64_t T, const float *fb /*dev*/, const int32_t *plan /*dev or NULL*/,
+                       const int32_t *desc /*host or NULL*/, int n_mels, float power,
+                       float *out /*dev*/, uint32_t *max_key_dev /*dev or NULL*/, void *stream);
+
 /* irfft of every frame: S (B,F,T) complex64 -> frames (B,T,n_fft) float32,
  * 1/n_fft scaled; imaginary parts of the DC and Nyquist bins are ignored —
  * mx.fft.irfft(·, n=n_fft) at stft.py:292-295 (incl. the transpose). */
@@ -290,7 +299,8 @@ int ap_dct_f32(const float *x /*dev*/, const float *C /*dev (n_out,n_in)*/,
 int ap_db_dct_f32(const float *S /*dev*/, const float *C /*dev (n_out,n_in)*/,
                   const float *row_scale /*dev or NULL*/, int64_t outer, int n_in, int64_t inner,
                   int n_out, float coef, float amin, float ref_value, const uint32_t *ref_key_dev,
-                  float top_db, uint32_t *ws_dev, float *out /*dev*/, void *stream);
+                  float top_db, uint32_t *ws_dev, int max_ready /* *ws_dev already holds max(S) */,
+                  float *out /*dev*/, void *stream);
 
 #ifdef __cplusplus
 }

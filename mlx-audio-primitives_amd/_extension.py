@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ap_mel_filterbank_host", "ap_dct_matrix_host", "ap_twiddle_table_host", "ap_fft_supported",
     "ap_mel_plan_words", "ap_mel_plan_host",
     "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
-    "ap_stft_f32", "ap_melspec_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_workspace_floats",
+    "ap_stft_f32", "ap_melspec_f32", "ap_melspec_max_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_workspace_floats",
     "ap_magnitude_f32", "ap_phase_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
@@ -77,6 +77,7 @@ def _declare(lib) -> None:
         "ap_overlap_add_f32": [P, P, L, L, I, I, L, L, P, P],
         "ap_stft_f32": [P, L, L, I, I, P, P, I, I, L, P, P],
         "ap_melspec_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P],
+        "ap_melspec_max_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P, P],
         "ap_mel_plan_host": [P, I, I, P, P],
         "ap_irfft_frames_f32": [P, L, L, I, P, P, P],
         "ap_istft_f32": [P, L, L, I, I, P, P, P, L, L, P, P],
@@ -90,7 +91,7 @@ def _declare(lib) -> None:
         "ap_to_db_f32": [P, L, F, F, F, P, F, P, P, P],
         "ap_from_db_f32": [P, L, F, F, P, P],
         "ap_dct_f32": [P, P, P, L, I, L, I, P, P],
-        "ap_db_dct_f32": [P, P, P, L, I, L, I, F, F, F, P, F, P, P, P],
+        "ap_db_dct_f32": [P, P, P, L, I, L, I, F, F, F, P, F, P, I, P, P],
         "ap_cfft_split_host": [L, P, P],
         "ap_pcg64_uniform_f32": [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                  ctypes.c_double, ctypes.c_double, L, P, P],

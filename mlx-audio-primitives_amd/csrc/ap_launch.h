@@ -202,6 +202,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.partial_stride = (W.n_slots + 1 + 3 + 3) & ~3;
     W.rowstart = plan + desc[10];
     W.out = P.out_mel;
+    W.max_key = nullptr;
     W.L = P.L;
     W.T = P.T;
     W.tiles_per_clip = (P.T + APW_G - 1) / APW_G;

@@ -21,6 +21,7 @@ struct ApMelWaveParams {
     const float *quads;        // (n_quads, 4) lane-interleaved filter weights: group i at first quad + 64 i
     const int32_t *rowstart;   // (M+1) slot range of every row
     float *out;                // (B, M, T)
+    unsigned *max_key;         // NULL, or the order-preserving key of max(out) to raise (one atomic per wave)
     int64_t L, T, tiles_per_clip, n_tiles, n_clips;
     int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots;   // n_slots: partial sums per frame
     int hopj;                  // hop / 128 when the next frame reuses this one's registers (2, 4, 8), else 0

@@ -46,6 +46,8 @@ static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) 
     return ap_check_launch("ap_melspec_f32(wave)");
 }
 
+static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
+
 // compile-time specialised engine for n_fft = 400 / 512 / 1024 (kernels_ct.h)
 template <int EPI, int PADGEN>
 static int ap_launch_ct(ApStftParams &P, int n_fft, int64_t B, void *stream, bool *handled) {
@@ -159,6 +161,14 @@ int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, con
                    const float *tw, int center, int pad_mode, int64_t T, const float *fb,
                    const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,
                    void *stream) {
+    return ap_melspec_max_f32(y, B, L, n_fft, hop, window, tw, center, pad_mode, T, fb, plan, desc, n_mels,
+                              power, out, nullptr, stream);
+}
+
+int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                       const float *tw, int center, int pad_mode, int64_t T, const float *fb,
+                       const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,
+                       uint32_t *max_key_dev, void *stream) {
     ApStftParams P;
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
@@ -168,6 +178,11 @@ int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, con
         ApMelWaveParams W;
         int grid = 0;
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
+            if (max_key_dev) {            // the kernel raises the key itself: one atomic per wave
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+                if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+                W.max_key = max_key_dev;
+            }
             // constant padding (or no centring) needs no index remap: bounds-checked buffer loads
             if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
                 return ap_launch_mel_wave_p<0>(W, grid, power, stream);
@@ -178,13 +193,16 @@ int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, con
         bool handled = false;
         rc = (P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? ap_launch_ct<1, 0>(P, n_fft, B, stream, &handled)
                                                            : ap_launch_ct<1, 1>(P, n_fft, B, stream, &handled);
-        if (rc != AP_OK || handled) return rc;
+        if (rc != AP_OK) return rc;
+        if (handled) return max_key_dev ? ap_reduce_max_f32(out, B * (int64_t)n_mels * T, max_key_dev, stream) : AP_OK;
     }
     rc = ap_allow_lds(ap_stft_generic_kernel<1>, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(ap_stft_generic_kernel<1>, dim3((unsigned)(P.tiles_per_clip * B)),
                        dim3(AP_BLOCK), P.tile.lds_bytes, (hipStream_t)stream, P);
-    return ap_check_launch("ap_melspec_f32");
+    rc = ap_check_launch("ap_melspec_f32");
+    if (rc != AP_OK || !max_key_dev) return rc;
+    return ap_reduce_max_f32(out, B * (int64_t)n_mels * T, max_key_dev, stream);
 }
 
 int ap_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const float *tw,
@@ -338,7 +356,6 @@ int ap_griffinlim_f32(const float *S, const float *angles, int64_t B, int64_t T,
     return ap_istft_f32(rebuilt, B, T, n_fft, hop, window, tw, frames_ws, out_offset, y_len, y, stream);
 }
 
-static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
 
 int ap_reduce_max_f32(const float *x, int64_t n, uint32_t *key_dev, void *stream) {
     if (!x || !key_dev || n <= 0) AP_FAIL(AP_ERR_INVALID, "reduce_max: bad arguments");
@@ -425,7 +442,8 @@ int ap_dct_f32(const float *x, const float *C, const float *row_scale, int64_t o
 
 int ap_db_dct_f32(const float *S, const float *C, const float *row_scale, int64_t outer, int n_in,
                   int64_t inner, int n_out, float coef, float amin, float ref_value,
-                  const uint32_t *ref_key_dev, float top_db, uint32_t *ws_dev, float *out, void *stream) {
+                  const uint32_t *ref_key_dev, float top_db, uint32_t *ws_dev, int max_ready, float *out,
+                  void *stream) {
     if (!S || !C || !out) AP_FAIL(AP_ERR_INVALID, "db_dct: NULL buffer");
     if (n_in <= 0 || n_out <= 0) AP_FAIL(AP_ERR_INVALID, "db_dct: sizes must be positive");
     if (outer <= 0 || inner <= 0) return AP_OK;
@@ -433,7 +451,7 @@ int ap_db_dct_f32(const float *S, const float *C, const float *row_scale, int64_
     if (clip && !ws_dev) AP_FAIL(AP_ERR_INVALID, "db_dct: top_db needs a scratch word");
     if (n_in * (n_out <= 16 ? 16 : 32) * (int)sizeof(float) > 64 * 1024)
         AP_FAIL(AP_ERR_UNSUPPORTED, "db_dct: n_in=%d too long for the fused kernel (use ap_to_db_f32 + ap_dct_f32)", n_in);
-    if (clip) {
+    if (clip && !max_ready) {
         int rc = ap_reduce_max_f32(S, outer * n_in * inner, ws_dev, stream);
         if (rc != AP_OK) return rc;
     }

@@ -22,6 +22,25 @@
 #define AP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// order-preserving float <-> uint key so a float max can use an integer atomic
+AP_DEV unsigned ap_fkey(float f) {
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+AP_DEV float ap_fkey_inv(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+#ifdef AP_HOST_EMU
+inline void ap_atomic_max_u32(unsigned *p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+#else
+AP_DEV void ap_atomic_max_u32(unsigned *p, unsigned v) { atomicMax(p, v); }
+#endif
+
 // ---- complex arithmetic on one (re, im) register pair ---------------------------------
 // Device build: packed-f32 instructions.  The compiler folds whole-vector negations and
 // component swaps into VOP3P op_sel modifiers but not the half negations a multiply by -i or a

@@ -67,25 +67,6 @@ ap_gl_project2_kernel(const float *S, const ap_float2 *Rcur, const ap_float2 *Rp
     }
 }
 
-// order-preserving float <-> uint key so a float max can use an integer atomic
-AP_DEV unsigned ap_fkey(float f) {
-    const unsigned u = __builtin_bit_cast(unsigned, f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-AP_DEV float ap_fkey_inv(unsigned k) {
-    const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-    return __builtin_bit_cast(float, u);
-}
-
-#ifdef AP_HOST_EMU
-inline void ap_atomic_max_u32(unsigned *p, unsigned v) {
-    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
-    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
-}
-#else
-AP_DEV void ap_atomic_max_u32(unsigned *p, unsigned v) { atomicMax(p, v); }
-#endif
-
 // per-workgroup max of x -> one integer atomic per workgroup on *key (order-preserving key)
 __global__ void __launch_bounds__(AP_BLOCK) ap_reduce_max_kernel(const float *x, int64_t n, unsigned *key) {
     float *red = reinterpret_cast<float *>(ap_smem);

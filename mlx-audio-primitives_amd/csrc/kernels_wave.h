@@ -270,6 +270,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
     const int64_t n_workers = (int64_t)gridDim.x * APW_WAVES;
     const int64_t n_frames = P.n_clips * P.T;
     const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
+    float vmax = -INFINITY;           // running max of this lane's mel values (mfcc's top_db clip needs the global one)
     ap_float2 raw[16];
     auto load_frame = [&](int64_t f) {
         const int64_t b = f / P.T;
@@ -413,13 +414,17 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
                 sum += cnt > 3 ? p3 : 0.0f;
                 if (P.max_row_parts > 4)                           // wave-uniform, rare
                     for (int j = rs0[i] + 4; j < rs1[i]; ++j) sum += partial[j];
-                if (row < M) otile[g * P.otile_stride + row] = sum;
+                if (row < M) {
+                    otile[g * P.otile_stride + row] = sum;
+                    vmax = fmaxf(vmax, sum);
+                }
             }
             for (int row = lane + 128; row < M; row += 64) {       // n_mels > 128
                 const int a0 = P.rowstart[row], a1 = P.rowstart[row + 1];
                 float sum = 0.0f;
                 for (int j = a0; j < a1; ++j) sum += partial[j];
                 otile[g * P.otile_stride + row] = sum;
+                vmax = fmaxf(vmax, sum);
             }
             AP_WAVE_SYNC();
         }
@@ -430,6 +435,15 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
         }
         AP_WAVE_SYNC();
         f += Gt;
+    }
+    if (P.max_key) {                  // one atomic per wave: lanes -> LDS -> lane 0
+        partial[lane] = vmax;
+        AP_WAVE_SYNC();
+        if (lane == 0) {
+            float m = partial[0];
+            for (int i = 1; i < 64; ++i) m = fmaxf(m, partial[i]);
+            ap_atomic_max_u32(P.max_key, ap_fkey(m));
+        }
     }
 }
 

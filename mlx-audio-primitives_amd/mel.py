@@ -113,10 +113,11 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
                    win_length: int | None = None, window="hann", center: bool = True,
                    pad_mode: str = "constant", power: float = 2.0, n_mels: int = 128,
                    fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
-                   norm: str | None = "slaney") -> torch.Tensor:
+                   norm: str | None = "slaney", _max_key: torch.Tensor | None = None) -> torch.Tensor:
     """mel_basis @ |stft(y)|**power (reference mel.py:245-352), fused on the GPU.
 
-    Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32."""
+    Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32.  ``_max_key`` (internal,
+    mfcc): a 1-element int32 device tensor that receives the order-preserving key of max(out)."""
     hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
     y = _x.to_device_f32(y)
     one_d = y.ndim == 1
@@ -132,10 +133,12 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
     out = torch.empty((B, n_mels, T), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
         tw = _get_twiddles(n_fft, dev)
-        _x.check(_x.lib().ap_melspec_f32(
+        _x.check(_x.lib().ap_melspec_max_f32(
             _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
             _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_mels),
-            float(power), _x.ptr(out), _x.stream_ptr(dev)))
+            float(power), _x.ptr(out), None if _max_key is None else _max_key.data_ptr(),
+            _x.stream_ptr(dev)))
     else:
         out.zero_()
+        _max_key = None
     return out[0] if one_d else out

@@ -65,10 +65,17 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
     Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames)."""
     validate_positive(n_mfcc, "n_mfcc")
     provided = S is not None
+    max_key = None
     if S is None:
+        # the mel kernel also leaves max(S) for the top_db clip of the dB stage (one atomic per wave)
+        y = _x.to_device_f32(y)
+        max_key = torch.empty(1, dtype=torch.int32, device=y.device)
         S = melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop_length, win_length=win_length,
                            window=window, center=center, pad_mode=pad_mode, power=power,
-                           n_mels=n_mels, fmin=fmin, fmax=fmax, htk=htk, norm=mel_norm)
+                           n_mels=n_mels, fmin=fmin, fmax=fmax, htk=htk, norm=mel_norm,
+                           _max_key=max_key)
+        if S.numel() == 0:
+            max_key = None
     else:
         S = _x.to_device_f32(S)
     batched = S.ndim == 3
@@ -83,11 +90,11 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
         # a provided S is taken to be log-power already (mfcc.py:253-258)
         M = dct(S, type=dct_type, n=n_mfcc, axis=1, norm=norm, _row_scale=lift)
     else:
-        M = _db_dct(S, dct_type, n_mfcc, norm, lift)
+        M = _db_dct(S, dct_type, n_mfcc, norm, lift, max_key)
     return M if batched else M[0]
 
 
-def _db_dct(S: torch.Tensor, dct_type: int, n_mfcc: int, norm, lift) -> torch.Tensor:
+def _db_dct(S: torch.Tensor, dct_type: int, n_mfcc: int, norm, lift, max_key=None) -> torch.Tensor:
     """power_to_db(S, ref=1.0, amin=1e-10, top_db=80.0) followed by the DCT along axis 1
     (mfcc.py:259-287) in one pass over S: ap_db_dct_f32 converts on load, so the dB array is
     never written.  Falls back to the two calls when the basis does not fit LDS."""
@@ -100,8 +107,9 @@ def _db_dct(S: torch.Tensor, dct_type: int, n_mfcc: int, norm, lift) -> torch.Te
     C = _dct_matrix(int(n_mfcc), int(n_in), norm, S.device)
     out = torch.empty((B, int(n_mfcc), inner), dtype=torch.float32, device=S.device)
     if out.numel():
-        ws = torch.empty(1, dtype=torch.int32, device=S.device)
+        ws = max_key if max_key is not None else torch.empty(1, dtype=torch.int32, device=S.device)
         _x.check(_x.lib().ap_db_dct_f32(_x.ptr(S), _x.ptr(C), None if lift is None else _x.ptr(lift),
                                         B, int(n_in), inner, int(n_mfcc), 10.0, 1e-10, 1.0, None, 80.0,
-                                        ws.data_ptr(), _x.ptr(out), _x.stream_ptr(S.device)))
+                                        ws.data_ptr(), int(max_key is not None), _x.ptr(out),
+                                        _x.stream_ptr(S.device)))
     return out

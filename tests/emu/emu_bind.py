@@ -95,7 +95,7 @@ def mel_plan(fb):
 
 
 def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, banded=True,
-            force_generic=False):
+            force_generic=False, return_max=False):
     y = np.ascontiguousarray(y, np.float32)
     B, L = y.shape
     T = n_frames(L, n_fft, hop, center)
@@ -113,9 +113,14 @@ def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, bande
         plan_p, desc_p = plan.ctypes.data_as(_i32p), desc.ctypes.data_as(_i32p)
     else:
         plan_p = desc_p = None
+    key = ctypes.c_uint32(0)
     _check(lib().emu_melspec_f32(_p(y), _i64(B), _i64(L), n_fft, hop, _p(window), _p(tw),
                                  int(center), pad_mode, _i64(T), _p(fb), plan_p, desc_p, M,
-                                 ctypes.c_float(power), _p(out)))
+                                 ctypes.c_float(power), _p(out), ctypes.byref(key) if return_max else None))
+    if return_max:
+        k = key.value                               # order-preserving key -> float (ap_fkey_inv)
+        u = (k & 0x7FFFFFFF) if (k & 0x80000000) else (~k & 0xFFFFFFFF)
+        return out, np.array([u], np.uint32).view(np.float32)[0]
     return out
 
 

@@ -88,7 +88,8 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
 
 int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
                     const float *tw, int center, int pad_mode, int64_t T, const float *fb,
-                    const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out) {
+                    const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,
+                    unsigned *max_key) {
     ApStftParams P;
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
@@ -99,6 +100,7 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         int grid = 0;
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
             if (grid > 1) grid = 1;   // exercise the persistent tile loop
+            if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
             const bool gen = !(W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT);
             if (power == 2.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 0>(W); });
             else if (power == 2.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 1>(W); });

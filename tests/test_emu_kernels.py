@@ -87,10 +87,11 @@ def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
     fb = ao.mel_filterbank(sr, 2048, M, **kw)
     plan, desc = eb.mel_plan(fb)
     assert desc[0] & 2 and desc[1] == M
-    A = eb.melspec(y, 2048, 512, win, fb, power=power, pad_mode=PM[pad_mode])
+    A, amax = eb.melspec(y, 2048, 512, win, fb, power=power, pad_mode=PM[pad_mode], return_max=True)
     R = ao.melspectrogram(y, sr=sr, n_fft=2048, hop_length=512, n_mels=M, power=power,
                           pad_mode=pad_mode, **kw)
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()            # the key the kernel raises for mfcc's top_db clip
 
 
 @pytest.mark.parametrize("hop", [256, 1024, 500, 128])
