@@ -146,11 +146,14 @@ int ap_stft_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop
  *   desc[7] n_parts          desc[8] off quads[n_quads][4] float weights   desc[9] n_quads
  *   desc[10] off rowstart[M+1]: row m's partial sums live in slots [rowstart[m], rowstart[m+1])
  *   desc[11] off wave_parts[n_wave_parts][4]: the same parts dealt to wavefront lanes (entry
- *            64 p + l = lane l of pass p), ordered so that the 16-byte LDS reads of one pass fall
- *            into different banks; an idle lane has n_groups = 0, slot = n_parts (a dump slot)
- *            and all-zero weights; 4th field = first quad in
- *   desc[13] off wave_quads[n_wave_quads][4]: lane-interleaved weights, always 4 groups per entry
- *            (zero past the part's end), group i at first quad + 64 i
+ *            64 p + l = lane l of pass p) as (slot A, group A, slot B, group B): the entry's
+ *            weight rows 0-1 go with |X|^p groups A, A+1 and sum into slot A, rows 2-3 go with
+ *            groups B, B+1 and sum into slot B - a second part of <= 2 groups - or, slot B = -1,
+ *            on top of slot A (one part of 3-4 groups), or into the dump slot n_parts (nothing
+ *            there; an idle lane has both slots = n_parts).  Entries are ordered so that the
+ *            16-byte LDS reads of one pass fall into different banks
+ *   desc[13] off wave_quads[n_wave_quads][4]: lane-interleaved weights, row i of entry 64 p + l at
+ *            256 p + 64 i + l (zero where a part ends)
  *   desc[12] n_wave_parts (multiple of 64)   desc[14] n_wave_quads = 4 n_wave_parts
  *   desc[15] largest number of parts of one row
  * Parts split each filter's span into runs of <= 4 aligned 4-bin groups, sorted by

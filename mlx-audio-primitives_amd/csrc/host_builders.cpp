@@ -214,8 +214,10 @@ void mel_analyse(const float *fb, int M, int F, std::vector<int> &lo, std::vecto
 // allows it; the weight quads are stored lane-interleaved (group i of entry e at
 // qw(e) + 64 i), which makes every weight read of a pass one contiguous 1 KiB row.
 struct MelWaveLayout {
-    std::vector<int> entry;        // 64 * passes: index into parts, or -1 (idle lane)
-    std::vector<int> qw;           // first quad of every entry
+    // 64 * passes entries; an entry computes two half sums: A over weight rows 0-1 (|X|^p groups
+    // gA, gA + 1) and B over rows 2-3 (groups gB, gB + 1).  A part of 3-4 groups takes a whole
+    // entry (gB = gA + 2, both halves go to its slot); two parts of <= 2 groups share one.
+    std::vector<int> partA, partB;     // index into parts, or -1
     int n_quads = 0;
 };
 
@@ -226,19 +228,21 @@ const int kB128Groups[4][16] = {
     {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
 
 void mel_wave_layout(const std::vector<MelPart> &parts, MelWaveLayout &L) {
-    const int n = (int)parts.size();
+    // parts are sorted by length (longest first): whole entries first, then the pairs
+    std::vector<std::pair<int, int>> ent;
+    size_t i = 0;
+    for (; i < parts.size() && parts[i].ng > 2; ++i) ent.push_back({(int)i, -1});
+    for (; i < parts.size(); i += 2) ent.push_back({(int)i, i + 1 < parts.size() ? (int)i + 1 : -1});
+    const int n = (int)ent.size();
     const int passes = (n + 63) / 64;
-    L.entry.assign((size_t)passes * 64, -1);
-    L.qw.assign((size_t)passes * 64, 0);
-    // every pass owns four 64-quad rows whatever its longest part is, and every entry (idle lanes
-    // too) points at its own column of them: the kernel reads 4 weight quads per lane without a
-    // branch and the ones past a part's end are zero
-    for (int ps = 0; ps < passes; ++ps)
-        for (int lane = 0; lane < 64; ++lane) L.qw[(size_t)ps * 64 + lane] = ps * 256 + lane;
+    L.partA.assign((size_t)passes * 64, -1);
+    L.partB.assign((size_t)passes * 64, -1);
     for (int ps = 0; ps < passes; ++ps) {
         const int first = ps * 64, last = first + 64 < n ? first + 64 : n;
+        // deal the entries of the pass to the four 16-lane groups of a ds_read_b128 so that their
+        // first |X|^p groups fall into different banks (distinct modulo 16) where the plan allows
         std::vector<int> bucket[16];
-        for (int i = first; i < last; ++i) bucket[parts[i].g0 & 15].push_back(i);
+        for (int e = first; e < last; ++e) bucket[parts[ent[e].first].g0 & 15].push_back(e);
         int order[16];
         for (int r = 0; r < 16; ++r) order[r] = r;
         std::stable_sort(order, order + 16, [&](int a, int b) { return bucket[a].size() > bucket[b].size(); });
@@ -259,9 +263,13 @@ void mel_wave_layout(const std::vector<MelPart> &parts, MelWaveLayout &L) {
             }
         }
         for (int g = 0; g < 4; ++g)
-            for (size_t j = 0; j < grp[g].size(); ++j)
-                L.entry[(size_t)ps * 64 + kB128Groups[g][j]] = grp[g][j];
+            for (size_t j = 0; j < grp[g].size(); ++j) {
+                const size_t slot = (size_t)ps * 64 + kB128Groups[g][j];
+                L.partA[slot] = ent[grp[g][j]].first;
+                L.partB[slot] = ent[grp[g][j]].second;
+            }
     }
+    // every pass owns four 64-quad weight rows; entry e = 64 p + l reads row i at 256 p + 64 i + l
     L.n_quads = passes * 256;
 }
 }  // namespace
@@ -276,7 +284,7 @@ int64_t ap_mel_plan_words(const float *fb, int n_mels, int n_bins) {
     MelWaveLayout L;
     mel_wave_layout(parts, L);
     return 2 * (int64_t)n_mels + 4 * (int64_t)parts.size() + 4 * quads + (int64_t)n_mels + 1 + 8 +
-           4 * (int64_t)L.entry.size() + 4 * (int64_t)L.n_quads + 8;
+           4 * (int64_t)L.partA.size() + 4 * (int64_t)L.n_quads + 8;
 }
 
 int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int32_t *desc) {
@@ -303,7 +311,7 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     off += off & 3 ? 4 - (off & 3) : 0;
     MelWaveLayout WL;
     mel_wave_layout(parts, WL);
-    const int64_t off_wparts = off; off += 4 * (int64_t)WL.entry.size();
+    const int64_t off_wparts = off; off += 4 * (int64_t)WL.partA.size();
     const int64_t off_wquads = off; off += 4 * (int64_t)WL.n_quads;
     for (int m = 0; m < M; ++m) { plan[off_lo + m] = lo[m]; plan[off_len + m] = len[m]; }
     bool parts_ok = true;
@@ -333,23 +341,34 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     for (int m = 0; m < M; ++m)
         if (plan[off_rs + m + 1] - plan[off_rs + m] > max_row_parts)
             max_row_parts = plan[off_rs + m + 1] - plan[off_rs + m];
-    for (size_t e = 0; e < WL.entry.size(); ++e) {
-        if (WL.entry[e] < 0) {
-            // idle lane: group 0 with all-zero weights, partial sum dumped past the last slot
-            plan[off_wparts + 4 * e + 0] = (int32_t)parts.size();
-            plan[off_wparts + 4 * e + 3] = WL.qw[e];
-            continue;
-        }
-        const MelPart &p = parts[WL.entry[e]];
-        plan[off_wparts + 4 * e + 0] = p.slot;
-        plan[off_wparts + 4 * e + 1] = p.g0;
-        plan[off_wparts + 4 * e + 2] = p.ng;
-        plan[off_wparts + 4 * e + 3] = WL.qw[e];
-        for (int g = 0; g < p.ng; ++g)
+    const int32_t dump = (int32_t)parts.size();              // slot past the last one: sums nobody reads
+    auto put_rows = [&](size_t e, int row0, const MelPart &p, int g_first, int g_count) {
+        const size_t col = (e / 64) * 256 + (e % 64);
+        for (int g = 0; g < g_count; ++g)
             for (int c = 0; c < 4; ++c) {
-                const int k = 4 * (p.g0 + g) + c;
-                wwq[4 * ((size_t)WL.qw[e] + 64 * (size_t)g) + c] = k < F ? fb[(size_t)p.row * F + k] : 0.0f;
+                const int k = 4 * (p.g0 + g_first + g) + c;
+                wwq[4 * (col + 64 * (size_t)(row0 + g)) + c] =
+                    (g_first + g < p.ng && k < F) ? fb[(size_t)p.row * F + k] : 0.0f;
             }
+    };
+    for (size_t e = 0; e < WL.partA.size(); ++e) {
+        int32_t *d = plan + off_wparts + 4 * e;                // slot A, group A, slot B, group B
+        d[0] = dump; d[1] = 0; d[2] = dump; d[3] = 0;          // idle lane: zero weights, group 0
+        if (WL.partA[e] < 0) continue;
+        const MelPart &pa = parts[WL.partA[e]];
+        d[0] = pa.slot;
+        d[1] = pa.g0;
+        put_rows(e, 0, pa, 0, 2);
+        if (WL.partB[e] >= 0) {                                // a second short part in rows 2-3
+            const MelPart &pb = parts[WL.partB[e]];
+            d[2] = pb.slot;
+            d[3] = pb.g0;
+            put_rows(e, 2, pb, 0, 2);
+        } else {                                               // rows 2-3 continue part A
+            d[2] = pa.ng > 2 ? -1 : dump;                      // -1: half B belongs to slot A
+            d[3] = pa.g0 + 2;
+            put_rows(e, 2, pa, 2, 2);
+        }
     }
     desc[0] = AP_PLAN_BANDED | (parts_ok ? AP_PLAN_PARTS : 0);
     desc[1] = M;
@@ -363,7 +382,7 @@ int ap_mel_plan_host(const float *fb, int n_mels, int n_bins, int32_t *plan, int
     desc[9] = (int32_t)quads;
     desc[10] = (int32_t)off_rs;
     desc[11] = (int32_t)off_wparts;
-    desc[12] = (int32_t)WL.entry.size();
+    desc[12] = (int32_t)WL.partA.size();
     desc[13] = (int32_t)off_wquads;
     desc[14] = (int32_t)WL.n_quads;
     desc[15] = max_row_parts;

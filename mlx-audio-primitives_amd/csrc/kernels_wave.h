@@ -357,46 +357,52 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             }
             AP_WAVE_SYNC();
             // ---- mel contraction of this frame by its own wave (no workgroup barrier) ----
-            // The lane's part descriptors are frame-invariant (registers).  No branch inside a pass:
-            // every lane reads 4 weight quads (zero past its part's end, all zero for an idle lane,
-            // whose sum goes to a dump slot) and 4 |X|^p quads, all 8 reads in flight together -
-            // with per-group branches the compiler fenced every read with an s_waitcnt.
+            // The lane's entry descriptors are frame-invariant (registers): (slot A, group A, slot B,
+            // group B).  No branch inside a pass: every lane reads its 4 weight quads (rows 0-1 go
+            // with |X|^p groups gA, gA + 1, rows 2-3 with gB, gB + 1; zero where a part ends or the
+            // lane is idle) and 4 |X|^p quads, all 8 reads in flight together - with per-group
+            // branches the compiler fenced every read with an s_waitcnt.  Half A goes to slot A;
+            // half B to slot B (a second short part), or on top of half A (slot B = -1: one long
+            // part), or to the dump slot.
 #pragma unroll
             for (int ps = 0; ps < APW_PASSES; ++ps) {
                 if (64 * ps < P.n_parts) {                         // wave-uniform
-                    const ap_int4 pd = mypart[ps];                 // slot, g0, ng, q0
-                    const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
-                    const ap_float4 *wq = WQ + pd.w;
+                    const ap_int4 pd = mypart[ps];
+                    const ap_float4 *pqa = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                    const ap_float4 *pqb = reinterpret_cast<const ap_float4 *>(pp) + pd.w;
+                    const ap_float4 *wq = WQ + 256 * ps + lane;
                     ap_float4 w[4], q[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { w[i] = wq[64 * i]; q[i] = pq[i]; }
-                    float acc = 0.0f;
+                    for (int i = 0; i < 4; ++i) w[i] = wq[64 * i];
+                    q[0] = pqa[0]; q[1] = pqa[1]; q[2] = pqb[0]; q[3] = pqb[1];
+                    float acc[2] = {0.0f, 0.0f};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc = fmaf(w[i].x, q[i].x, acc);
-                        acc = fmaf(w[i].y, q[i].y, acc);
-                        acc = fmaf(w[i].z, q[i].z, acc);
-                        acc = fmaf(w[i].w, q[i].w, acc);
+                        acc[i >> 1] = fmaf(w[i].x, q[i].x, acc[i >> 1]);
+                        acc[i >> 1] = fmaf(w[i].y, q[i].y, acc[i >> 1]);
+                        acc[i >> 1] = fmaf(w[i].z, q[i].z, acc[i >> 1]);
+                        acc[i >> 1] = fmaf(w[i].w, q[i].w, acc[i >> 1]);
                     }
-                    partial[pd.x] = acc;
+                    partial[pd.x] = pd.z < 0 ? acc[0] + acc[1] : acc[0];
+                    partial[pd.z < 0 ? P.n_slots : pd.z] = acc[1];
                 }
             }
-            for (int p0 = 64 * APW_PASSES; p0 < P.n_parts; p0 += 64) {   // plans with > 256 parts
-                const int pi = p0 + lane;
-                if (pi < P.n_parts) {
-                    const ap_int4 pd = PART[pi];
-                    const ap_float4 *pq = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
-                    const ap_float4 *wq = WQ + pd.w;
-                    float acc = 0.0f;
-                    for (int i = 0; i < pd.z; ++i) {
-                        const ap_float4 w = wq[64 * i], q = pq[i];
-                        acc = fmaf(w.x, q.x, acc);
-                        acc = fmaf(w.y, q.y, acc);
-                        acc = fmaf(w.z, q.z, acc);
-                        acc = fmaf(w.w, q.w, acc);
-                    }
-                    partial[pd.x] = acc;
+            for (int p0 = 64 * APW_PASSES; p0 < P.n_parts; p0 += 64) {   // plans with > 256 entries
+                const ap_int4 pd = PART[p0 + lane];
+                const ap_float4 *pqa = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                const ap_float4 *pqb = reinterpret_cast<const ap_float4 *>(pp) + pd.w;
+                const ap_float4 *wq = WQ + 4 * p0 + lane;
+                float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const ap_float4 w = wq[64 * i], q = (i & 2) ? pqb[i & 1] : pqa[i & 1];
+                    acc[i >> 1] = fmaf(w.x, q.x, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w.y, q.y, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w.z, q.z, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w.w, q.w, acc[i >> 1]);
                 }
+                partial[pd.x] = pd.z < 0 ? acc[0] + acc[1] : acc[0];
+                partial[pd.z < 0 ? P.n_slots : pd.z] = acc[1];
             }
             AP_WAVE_SYNC();
             // a row's partial sums are adjacent; frame t0+g is one column of this wave's
