@@ -1,12 +1,13 @@
-// Fused mel-spectrogram kernel for n_fft = 2048 on gfx950: one wavefront per frame.
+// Wave-per-frame kernels for n_fft = 2048 on gfx950: fused mel-spectrogram, STFT, irfft / ISTFT.
 //
-// Every wave64 is an independent worker: it takes tiles of 8 consecutive frames of one clip
-// and transforms ONE frame at a time entirely in its own registers + a wave-private LDS
-// exchange buffer (no s_barrier anywhere in the frame loop):
+// Mel: every wave64 is an independent worker that owns a contiguous stretch of the flattened
+// (clip, frame) stream and transforms ONE frame at a time entirely in its own registers + a
+// wave-private LDS exchange buffer (no s_barrier anywhere in the frame loop):
 //
-//   global samples (16 x 8 B per lane, prefetched one round ahead) * window (registers)
-//   radix-16 butterflies in registers                              [mx.fft.rfft, stft.py:130]
-//   * W_1024^(lane*k1) (registers) -> LDS transpose #1 (padded rows, ds_read_b128)
+//   global samples (bounds-checked buffer loads, one frame ahead; the samples two consecutive
+//   frames share stay in registers) * window (LDS table)
+//   radix-16 butterflies in registers, packed f32                  [mx.fft.rfft, stft.py:130]
+//   * W_1024^(lane*k1) (LDS table) -> LDS transpose #1 (conflict-free rows, ds_read_b128)
 //   radix-16 butterflies, * W_64^(a*c) (small LDS table)
 //   radix-4 across the 4 lanes of a quad with DPP quad_perm (no LDS round trip)
 //   LDS transpose #2 to natural order -> paired real-input split (bins k and 1024-k
@@ -14,14 +15,14 @@
 //
 // then the same wave contracts its plane with the mel filterbank (mx.matmul(mel_basis, S),
 // mel.py:344-350) from a host-built plan: every filter's span is cut into parts of <= 4
-// aligned 4-bin groups, sorted by length; a lane owns a part, does one ds_read_b128 of
-// weights + one of |X|^p per group, and the partial sums of a row (adjacent slots) are added
-// by the lane that owns the row and stored as one column of (B,M,T).  No atomics (LDS float
-// atomics cost ~3 cycles per lane on gfx950 and made the first version of this kernel
-// LDS-bound) and no workgroup barrier after the table set-up: the 12 waves of a workgroup
+// aligned 4-bin groups; a lane entry holds one long part or two short ones, reads 4 weight quads
+// + 4 |X|^p quads without a branch, and the partial sums of a row (adjacent slots) are added by
+// the lane that owns the row and stored as one column of the wave's output tile.  No atomics
+// (LDS float atomics cost ~3 cycles per lane on gfx950 and made the first version of this
+// kernel LDS-bound) and no workgroup barrier after the table set-up: the 8 waves of a workgroup
 // only share the read-only tables (window, twiddles, filter weights) in LDS.
 //
-// The complex 1024-point transform is 16 x 16 x 4.  Workgroups are persistent over tiles.
+// The complex 1024-point transform is 16 x 16 x 4.  Workgroups are persistent (one per CU).
 #pragma once
 #include "ap_wave_params.h"
 #include "fft_lds.h"
