@@ -24,8 +24,10 @@ AP_DEV void ap_stockham_pass_ct(const ap_float2 *in, ap_float2 *out, const ap_fl
     constexpr int PER = NC / R;
     constexpr int TMUL = (NC / (NS * R)) * 2;          // W_{NS*R}^1 in the W_n table (n = 2 NC)
     for (int item = tid; item < G * PER; item += NT) {
-        const int g = item / PER;
-        const int j = item - g * PER;
+        // frames fastest across lanes: G is a power of two (shifts instead of divisions by PER),
+        // and the frame stride FS = 4 (mod 32) spreads the 8 frames over the banks
+        const int g = item % G;
+        const int j = item / G;
         const ap_float2 *src = in + g * FS;
         ap_float2 *dst = out + g * FS;
         const int k = j % NS;
