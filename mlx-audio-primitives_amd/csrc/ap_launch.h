@@ -232,6 +232,55 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     return AP_OK;
 }
 
+// n_fft = 1024 wave-per-frame mel kernel (kernels_wave512.h): constant padding, plan with parts,
+// at most 128 filters (two rows per lane).  Returns 1 when it does not apply.
+struct ApMelWave512Params;
+template <class W512>
+static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t B, const int32_t *plan,
+                                         const int32_t *desc, int n_waves, int x_complex, int passes_reg,
+                                         int *grid) {
+    if (!(plan && desc && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
+    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (P.n_mels > 128) return 1;
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.parts = plan + desc[11];
+    W.n_parts = desc[12];
+    W.quads = reinterpret_cast<const float *>(plan + desc[13]);
+    W.n_quads = desc[14];
+    W.n_slots = desc[7];
+    W.max_row_parts = desc[15];
+    W.partial_stride = (W.n_slots + 1 + 3 + 3) & ~3;
+    if (W.partial_stride < 64) W.partial_stride = 64;          // the max reduction stages 64 lanes there
+    W.rowstart = plan + desc[10];
+    W.out = P.out_mel;
+    W.max_key = nullptr;
+    W.L = P.L;
+    W.T = P.T;
+    W.n_clips = B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    W.n_mels = P.n_mels;
+    W.power = P.power;
+    W.hopj = (P.hop == 128 || P.hop == 256 || P.hop == 512) ? P.hop / 128 : 0;
+    int off = n_waves * x_complex * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 8 * 64 * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += 512 * (int)sizeof(ap_float2);
+    W.off_wq = off; off += ap_align16(W.n_quads * 16);
+    W.off_parts = off; off += W.n_parts > 64 * passes_reg ? ap_align16(W.n_parts * 16) : 0;
+    W.off_partial = off; off += ap_align16(n_waves * W.partial_stride * 4);
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    const int64_t n_frames = B * P.T;
+    int64_t g = (n_frames + (int64_t)n_waves * 8 - 1) / ((int64_t)n_waves * 8);   // >= 8 frames per wave
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
 // LDS geometry of the compile-time engine (shared with kernels_ct.h).  The first pass (radix R0)
 // leaves its output transposed with the odd row stride PQ = (nc / R0) | 1, so a frame needs

@@ -13,6 +13,7 @@
 #include "kernels_pointwise.h"
 #include "kernels_bigfft.h"
 #include "kernels_ct.h"
+#include "kernels_wave512.h"
 
 static thread_local char g_err[512] = "";
 
@@ -187,6 +188,23 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
             if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
                 return ap_launch_mel_wave_p<0>(W, grid, power, stream);
             return ap_launch_mel_wave_p<1>(W, grid, power, stream);
+        }
+    }
+    if (n_fft == 1024) {
+        ApMelWave512Params W;
+        int grid = 0;
+        if (ap_prepare_mel_wave512(W, P, B, plan, desc, APH_WAVES, APH_X_COMPLEX, APH_PASSES, &grid) == AP_OK) {
+            if (max_key_dev) {
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+                if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+                W.max_key = max_key_dev;
+            }
+            auto kern = power == 2.0f ? ap_mel1024_wave_kernel<2> : power == 1.0f ? ap_mel1024_wave_kernel<1>
+                                                                                   : ap_mel1024_wave_kernel<0>;
+            rc = ap_allow_lds(kern, W.lds_bytes);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APH_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+            return ap_check_launch("ap_melspec_f32(wave512)");
         }
     }
     if (!(desc && (desc[0] & AP_PLAN_FORCE_GENERIC))) {

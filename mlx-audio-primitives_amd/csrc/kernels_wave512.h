@@ -1,0 +1,324 @@
+// Wave-per-frame fused mel-spectrogram for n_fft = 1024 on gfx950 (constant padding).
+//
+// The complex 512-point transform is 8 x 8 x 8 with 8 values per lane: three in-register
+// radix-8 passes around two wave-private LDS transposes whose layouts are conflict-free for
+// both the ds_write_b64 and the ds_read_b128 side (tools/lds_banks.py):
+//
+//   pass 1 over j (z[l + 64 j]), * W_512^(l k1)   -> T1: row 8 k1 + a of 10 complex, column b
+//   pass 2 over b (l = a + 8 b),  * W_64^(a c)    -> T2: 66 c + 8 k1 + a
+//   pass 3 over a                                  -> lane l = k1 + 8 c holds bins l + 64 e
+//
+// so after pass 3 every lane already owns the bins k = l + 64 r, r = 0..3, of the paired real
+// split and only their mirrors 512 - k (upper half, natural order) come back from LDS.
+// With 8 values per lane the kernel stays under 128 VGPRs: 16 waves per CU (the 2048 kernel:
+// 8), and the 8-frame output run of a lane's two mel rows lives in registers (each lane stores
+// 32 contiguous bytes per row), so a wave needs only its 5 KB exchange buffer in LDS.
+// Everything after the split - power, plan-based contraction, row sums - is the scheme of
+// kernels_wave.h.  Reference: mel.py:245-352 (stft.py:130 + mel.py:344-350).
+#pragma once
+#include "kernels_wave.h"
+
+#define APH_NC 512            // complex points
+#define APH_WAVES 16          // waves per workgroup (4 per SIMD)
+#define APH_X_COMPLEX 648     // exchange buffer: T1 64 x 10 = 640, T2 66 x 7 + 64 = 526, plane 516 floats
+#define APH_PASSES 3          // contraction passes whose descriptors live in registers (192 entries)
+#define APH_T1(r) ((r) * 10)
+#define APH_T2(c, k1) ((c) * 66 + (k1) * 8)
+
+// cos/sin(2 pi r / 16): W_1024^(64 r)
+#define APH_C16(r) ((float)__builtin_cos(6.283185307179586476925 * (r) / 16.0))
+#define APH_S16(r) ((float)__builtin_sin(6.283185307179586476925 * (r) / 16.0))
+
+struct ApMelWave512Params {
+    const float *y;            // (B, L)
+    const float *window;       // (1024)
+    const ap_float2 *tw;       // (1024) (cos, sin)(2 pi j / 1024)
+    const int32_t *parts;      // wave layout of the plan (include/audioprims.h, desc[11])
+    const float *quads;
+    const int32_t *rowstart;
+    float *out;                // (B, M, T)
+    unsigned *max_key;
+    int64_t L, T, n_clips;
+    int hop, pad, n_mels, n_parts, n_quads, n_slots, max_row_parts, partial_stride, hopj;
+    float power;
+    int off_tw1, off_tw2, off_win, off_wq, off_parts, off_partial, lds_bytes;
+};
+
+template <int PMODE>
+__global__ void __launch_bounds__(64 * APH_WAVES, 4) ap_mel1024_wave_kernel(ApMelWave512Params P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APH_X_COMPLEX;
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);   // [8][64]
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);   // [8][8]
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // [512] pairs
+    const ap_float4 *WQ = reinterpret_cast<const ap_float4 *>(ap_smem + P.off_wq);
+    const ap_int4 *PART = reinterpret_cast<const ap_int4 *>(ap_smem + P.off_parts);
+    float *partial = reinterpret_cast<float *>(ap_smem + P.off_partial) + wave * P.partial_stride;
+    const int M = P.n_mels;
+    {   // workgroup tables (once; the only workgroup barrier)
+        const int nt = 64 * APH_WAVES;
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        ap_float2 *win = reinterpret_cast<ap_float2 *>(ap_smem + P.off_win);
+        ap_float4 *wq = reinterpret_cast<ap_float4 *>(ap_smem + P.off_wq);
+        for (int i = tid; i < 8 * 64; i += nt) tw1[i] = P.tw[(2 * (i & 63) * (i >> 6)) & 1023];   // W_512^(l k1)
+        if (tid < 64) tw2[tid] = P.tw[16 * (tid >> 3) * (tid & 7)];                                // W_64^(a c)
+        for (int i = tid; i < APH_NC; i += nt) win[i] = reinterpret_cast<const ap_float2 *>(P.window)[i];
+        for (int i = tid; i < P.n_quads; i += nt) wq[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
+        if (P.n_parts > 64 * APH_PASSES) {
+            ap_int4 *part = reinterpret_cast<ap_int4 *>(ap_smem + P.off_parts);
+            for (int i = tid; i < P.n_parts; i += nt) part[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
+        }
+    }
+    const int la = lane & 7, lb = lane >> 3;
+    const ap_float2 tws0h = ap_scale(P.tw[lane], 0.5f);                      // W_1024^lane / 2
+    const ap_float2 half = ap_mk(0.5f, 0.5f);
+    float *pp = reinterpret_cast<float *>(X);                                 // |X|^p plane, aliased on X
+    ap_int4 mypart[APH_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < APH_PASSES; ++ps) {
+        const int pi = lane + 64 * ps;
+        mypart[ps].x = 0; mypart[ps].y = 0; mypart[ps].z = 0; mypart[ps].w = 0;
+        if (pi < P.n_parts) mypart[ps] = reinterpret_cast<const ap_int4 *>(P.parts)[pi];
+    }
+    int rs0[2], rs1[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lane + 64 * i;
+        rs0[i] = row < M ? P.rowstart[row] : 0;
+        rs1[i] = row < M ? P.rowstart[row + 1] : 0;
+    }
+    AP_LDS_BARRIER();
+
+    const int64_t worker = (int64_t)blockIdx.x * APH_WAVES + wave;
+    const int64_t n_workers = (int64_t)gridDim.x * APH_WAVES;
+    const int64_t n_frames = P.n_clips * P.T;
+    const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
+    float vmax = -INFINITY;
+    ap_float2 raw[8];
+    auto load_frame = [&](int64_t f) {
+        const int64_t b = f / P.T;
+        const int64_t t = f - b * P.T;
+        const ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+        const int64_t base = t * (int64_t)P.hop - P.pad;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t p = base + 2 * (lane + 64 * j);
+            raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+        }
+    };
+    // hop = 128 s: pair j of the next frame is pair j + s of this one (kernels_wave.h)
+    auto next_frame = [&](int64_t f) {
+        const int64_t b = f / P.T;
+        const int64_t t = f - b * P.T;
+        if (t == 0 || P.hopj == 0) { load_frame(f); return; }
+        const ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+        const int64_t base = t * (int64_t)P.hop - P.pad;
+#define APH_SHIFT_LOAD(S)                                                                    \
+        {                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 8 - (S); ++j) raw[j] = raw[j + (S)];       \
+            _Pragma("unroll") for (int j = 8 - (S); j < 8; ++j) {                             \
+                const int64_t p = base + 2 * (lane + 64 * j);                                \
+                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));            \
+            }                                                                                \
+        }
+        if (P.hopj == 2) APH_SHIFT_LOAD(2)
+        else if (P.hopj == 1) APH_SHIFT_LOAD(1)
+        else APH_SHIFT_LOAD(4)
+#undef APH_SHIFT_LOAD
+    };
+    if (f_lo < f_hi) load_frame(f_lo);
+
+    for (int64_t f = f_lo; f < f_hi;) {
+        const int64_t b = f / P.T;
+        const int64_t t0 = f - b * P.T;
+        int64_t run = P.T - t0;
+        if (run > 8) run = 8;
+        if (run > f_hi - f) run = f_hi - f;
+        const int Gt = (int)run;
+        float acc0[8], acc1[8];          // the run's values of rows lane and lane + 64 (newest last)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+
+        for (int g = 0; g < Gt; ++g) {
+            ap_float2 v[8];
+            {
+                ap_float2 w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = WIN[lane + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ap_mul2(raw[j], w[j]);
+            }
+            AP_SCHED_FENCE();
+            if (f + g + 1 < f_hi) next_frame(f + g + 1);
+            AP_SCHED_FENCE();
+            // ---- pass 1 over j, twiddle, transpose #1 ------------------------------------------
+            {
+                ap_float2 t1[8];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) t1[k] = TW1[k * 64 + lane];
+                ApButterfly<8>::run(v);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) X[APH_T1(8 * k + la) + lb] = v[k];
+            }
+            AP_WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = X[APH_T1(lane) + i];          // lane = (k1, a), register b
+            AP_WAVE_SYNC();
+            // ---- pass 2 over b, twiddle W_64^(a c), transpose #2 -------------------------------
+            {
+                ap_float2 t2[8];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) t2[c] = TW2[la * 8 + c];
+                ApButterfly<8>::run(v);
+#pragma unroll
+                for (int c = 1; c < 8; ++c) v[c] = ap_mul_fw(v[c], t2[c]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) X[APH_T2(c, lb) + la] = v[c];    // writer lane = (k1 = lb, a = la)
+            }
+            AP_WAVE_SYNC();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = X[APH_T2(lb, la) + i];         // reader lane = (c = lb, k1 = la)
+            AP_WAVE_SYNC();
+            // ---- pass 3 over a: this lane is (c = lb, k1 = la) and now holds Z[k1 + 8 c + 64 e] =
+            //      Z[lane + 64 e], e = 0..7 ------------------------------------------------------
+            ApButterfly<8>::run(v);
+            const int kl = lane;
+            // ---- mirrored half through LDS (natural order, upper half only), paired split ----
+#pragma unroll
+            for (int e = 4; e < 8; ++e) X[kl + 64 * (e - 4)] = v[e];          // Z[256 + kl + 64 (e-4)]
+            AP_WAVE_SYNC();
+            ap_float2 zm[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int km = (APH_NC - (kl + 64 * r)) & (APH_NC - 1);       // mirror bin
+                zm[r] = km >= 256 ? X[km - 256] : v[0];                       // km = 0 only for kl = 0, r = 0
+            }
+            const ap_float2 z256 = X[0];                                      // Z[256] (lane 0 uses it)
+            AP_WAVE_SYNC();
+            {
+                float pk[4], pm[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const ap_float2 a = ap_add_conj(v[r], zm[r]);
+                    const ap_float2 d = ap_sub_conj(v[r], zm[r]);
+                    const ap_float2 w = r == 0 ? tws0h : ap_mul_bw_c(tws0h, APH_C16(r), APH_S16(r));
+                    const ap_float2 u = ap_mul_fw(d, w);
+                    const ap_float2 xk = ap_fma_add_mi(a, half, u);
+                    const ap_float2 xm = ap_fma_sub_mi(a, half, u);
+                    pk[r] = apw_pow2x<PMODE>(xk.x, xk.y, P.power);
+                    pm[r] = apw_pow2x<PMODE>(xm.x, xm.y, P.power);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = kl + 64 * r;
+                    pp[k] = pk[r];
+                    pp[APH_NC - k] = pm[r];
+                }
+                if (lane == 0) pp[APH_NC / 2] = apw_pow2x<PMODE>(z256.x, z256.y, P.power);
+            }
+            AP_WAVE_SYNC();
+            // ---- plan-based contraction (kernels_wave.h) --------------------------------------------
+#pragma unroll
+            for (int ps = 0; ps < APH_PASSES; ++ps) {
+                if (64 * ps < P.n_parts) {
+                    const ap_int4 pd = mypart[ps];
+                    const ap_float4 *pqa = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                    const ap_float4 *pqb = reinterpret_cast<const ap_float4 *>(pp) + pd.w;
+                    const ap_float4 *wq = WQ + 256 * ps + lane;
+                    ap_float4 w[4], q[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = wq[64 * i];
+                    q[0] = pqa[0]; q[1] = pqa[1]; q[2] = pqb[0]; q[3] = pqb[1];
+                    float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i >> 1] = fmaf(w[i].x, q[i].x, acc[i >> 1]);
+                        acc[i >> 1] = fmaf(w[i].y, q[i].y, acc[i >> 1]);
+                        acc[i >> 1] = fmaf(w[i].z, q[i].z, acc[i >> 1]);
+                        acc[i >> 1] = fmaf(w[i].w, q[i].w, acc[i >> 1]);
+                    }
+                    partial[pd.x] = pd.z < 0 ? acc[0] + acc[1] : acc[0];
+                    partial[pd.z < 0 ? P.n_slots : pd.z] = acc[1];
+                }
+            }
+            for (int p0 = 64 * APH_PASSES; p0 < P.n_parts; p0 += 64) {
+                const ap_int4 pd = PART[p0 + lane];
+                const ap_float4 *pqa = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+                const ap_float4 *pqb = reinterpret_cast<const ap_float4 *>(pp) + pd.w;
+                const ap_float4 *wq = WQ + 4 * p0 + lane;
+                float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const ap_float4 w = wq[64 * i], q = (i & 2) ? pqb[i & 1] : pqa[i & 1];
+                    acc[i >> 1] = fmaf(w.x, q.x, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w.y, q.y, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w.z, q.z, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w.w, q.w, acc[i >> 1]);
+                }
+                partial[pd.x] = pd.z < 0 ? acc[0] + acc[1] : acc[0];
+                partial[pd.z < 0 ? P.n_slots : pd.z] = acc[1];
+            }
+            AP_WAVE_SYNC();
+            // ---- row sums into the run's registers (shift: newest value last) -------------------
+            float sum2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int cnt = rs1[i] - rs0[i];
+                const float p0 = partial[rs0[i]], p1 = partial[rs0[i] + 1], p2 = partial[rs0[i] + 2],
+                            p3 = partial[rs0[i] + 3];
+                float sum = cnt > 0 ? p0 : 0.0f;
+                sum += cnt > 1 ? p1 : 0.0f;
+                sum += cnt > 2 ? p2 : 0.0f;
+                sum += cnt > 3 ? p3 : 0.0f;
+                if (P.max_row_parts > 4)
+                    for (int j = rs0[i] + 4; j < rs1[i]; ++j) sum += partial[j];
+                sum2[i] = sum;
+                if (lane + 64 * i < M) vmax = fmaxf(vmax, sum);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { acc0[i] = acc0[i + 1]; acc1[i] = acc1[i + 1]; }
+            acc0[7] = sum2[0];
+            acc1[7] = sum2[1];
+            AP_WAVE_SYNC();
+        }
+        // ---- store the run: frame t0 + g sits in register 8 - Gt + g ------------------------------
+        {
+            float *ob = P.out + b * (int64_t)M * P.T + t0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = lane + 64 * i;
+                if (row < M) {
+                    float *dst = ob + (int64_t)row * P.T;
+                    const float *src = i == 0 ? acc0 : acc1;
+                    if (Gt == 8) {               // 32 contiguous bytes: two 16-byte stores (4-byte aligned)
+                        ap_rsp_f4u lo, hi;
+                        lo.x = src[0]; lo.y = src[1]; lo.z = src[2]; lo.w = src[3];
+                        hi.x = src[4]; hi.y = src[5]; hi.z = src[6]; hi.w = src[7];
+                        *reinterpret_cast<ap_rsp_f4u *>(dst) = lo;
+                        *reinterpret_cast<ap_rsp_f4u *>(dst + 4) = hi;
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 8; ++g)
+                            if (g >= 8 - Gt) dst[g - (8 - Gt)] = src[g];
+                    }
+                }
+            }
+        }
+        f += Gt;
+    }
+    if (P.max_key) {
+        AP_WAVE_SYNC();
+        partial[lane] = vmax;
+        AP_WAVE_SYNC();
+        if (lane == 0) {
+            float m = partial[0];
+            for (int i = 1; i < 64; ++i) m = fmaxf(m, partial[i]);
+            ap_atomic_max_u32(P.max_key, ap_fkey(m));
+        }
+    }
+}

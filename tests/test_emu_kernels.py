@@ -107,6 +107,21 @@ def test_emu_wave_kernel_hops(hop):
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("hop,M,L,B,power", [(256, 128, 9000, 2, 2.0), (128, 80, 5000, 1, 1.0),
+                                              (512, 64, 12000, 3, 2.0), (300, 40, 7000, 2, 1.5)])
+def test_emu_wave512_kernel(hop, M, L, B, power):
+    """kernels_wave512.h (n_fft=1024: 8 x 8 x 8 wave-per-frame transform, output run in registers):
+    register reuse across frames at hop 128 / 256 / 512, full loads otherwise, clip changes."""
+    rng = np.random.default_rng(hop + M)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 1024, 1024)
+    fb = ao.mel_filterbank(22050, 1024, M)
+    A, amax = eb.melspec(y, 1024, hop, win, fb, power=power, return_max=True)
+    R = ao.melspectrogram(y, sr=22050, n_fft=1024, hop_length=hop, n_mels=M, power=power)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()
+
+
 @pytest.mark.parametrize("n_fft,hop,L,B", [
     (512, 128, 4000, 2), (2048, 512, 9000, 1), (400, 160, 3000, 2), (27, 5, 300, 1),
     (30, 7, 300, 2), (8192, 2048, 20000, 1),

@@ -242,6 +242,19 @@ def test_melspectrogram_whisper_and_variants(batch_signals):
                                rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("hop,M,power,B,L", [(256, 128, 2.0, 3, 30000), (128, 80, 1.0, 2, 9000),
+                                              (512, 64, 2.0, 40, 22050), (300, 40, 1.5, 2, 8000)])
+def test_melspectrogram_1024_wave_kernel(hop, M, power, B, L):
+    """n_fft=1024 wave-per-frame kernel (8 x 8 x 8, output run in registers): register reuse
+    across frames at hop 128 / 256 / 512, full loads otherwise, many clips per wave stretch."""
+    rng = np.random.default_rng(hop + M)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    got = host(ap.melspectrogram(dev(y), sr=22050, n_fft=1024, hop_length=hop, n_mels=M, power=power))
+    want = ao.melspectrogram(y, sr=22050, n_fft=1024, hop_length=hop, n_mels=M, power=power)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
 def test_melspectrogram_paths_agree(random_signal):
     """Dense contraction, banded contraction (generic LDS engine) and the n_fft=2048 wave
     kernel.  Skipping filter zeros must not change a bit on the generic engine; the wave
