@@ -10,16 +10,17 @@
 //
 // so after pass 3 every lane already owns the bins k = l + 64 r, r = 0..3, of the paired real
 // split and only their mirrors 512 - k (upper half, natural order) come back from LDS.
-// With 8 values per lane the kernel stays under 128 VGPRs: 16 waves per CU (the 2048 kernel:
-// 8), and the 8-frame output run of a lane's two mel rows lives in registers (each lane stores
-// 32 contiguous bytes per row), so a wave needs only its 5 KB exchange buffer in LDS.
+// With 8 values per lane the kernel needs 147 VGPRs: 12 waves per CU (the 2048 kernel: 8; 16 waves
+// under 128 VGPRs spilled inside the frame loop and measured 0.28 against 0.24 ms), and the
+// 8-frame output run of a lane's two mel rows lives in registers (each lane stores 32 contiguous
+// bytes per row), so a wave needs only its 5 KB exchange buffer in LDS.
 // Everything after the split - power, plan-based contraction, row sums - is the scheme of
 // kernels_wave.h.  Reference: mel.py:245-352 (stft.py:130 + mel.py:344-350).
 #pragma once
 #include "kernels_wave.h"
 
 #define APH_NC 512            // complex points
-#define APH_WAVES 16          // waves per workgroup (4 per SIMD)
+#define APH_WAVES 12          // waves per workgroup (3 per SIMD)
 #define APH_X_COMPLEX 648     // exchange buffer: T1 64 x 10 = 640, T2 66 x 7 + 64 = 526, plane 516 floats
 #define APH_PASSES 3          // contraction passes whose descriptors live in registers (192 entries)
 #define APH_T1(r) ((r) * 10)
@@ -45,7 +46,7 @@ struct ApMelWave512Params {
 };
 
 template <int PMODE>
-__global__ void __launch_bounds__(64 * APH_WAVES, 4) ap_mel1024_wave_kernel(ApMelWave512Params P) {
+__global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMelWave512Params P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = AP_UNIFORM(tid >> 6);
