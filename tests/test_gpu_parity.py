@@ -255,6 +255,19 @@ def test_melspectrogram_1024_wave_kernel(hop, M, power, B, L):
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("kw", [dict(n_mels=160), dict(n_mels=64, pad_mode="reflect"),
+                                dict(n_mels=40, center=False, hop_length=100)])
+def test_melspectrogram_1024_fallbacks(kw):
+    """Shapes the n_fft=1024 wave kernel does not take (more than 128 filters, edge / reflect padding)
+    stay on the compile-time engine; center=False and an odd hop run on the wave kernel."""
+    rng = np.random.default_rng(11)
+    y = rng.standard_normal((3, 12000)).astype(np.float32)
+    got = host(ap.melspectrogram(dev(y), sr=22050, n_fft=1024, **kw))
+    want = ao.melspectrogram(y, sr=22050, n_fft=1024, **kw)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
 def test_melspectrogram_paths_agree(random_signal):
     """Dense contraction, banded contraction (generic LDS engine) and the n_fft=2048 wave
     kernel.  Skipping filter zeros must not change a bit on the generic engine; the wave
