@@ -281,6 +281,34 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
     return AP_OK;
 }
 
+// n_fft = 1024 STFT wave kernel geometry (kernels_wave512.h); returns 1 when it does not apply
+template <class W512>
+static inline int ap_prepare_stft_wave512(W512 &W, const ApStftParams &P, int64_t B, int n_waves,
+                                          int x_complex, int ob_complex, int *grid) {
+    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (P.T > (1 << 20)) return 1;                        // 32-bit row offsets in the store phase
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.out = P.out_c;
+    W.L = P.L;
+    W.T = P.T;
+    W.groups_per_clip = (P.T + n_waves - 1) / n_waves;
+    W.n_groups = W.groups_per_clip * B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    int off = n_waves * x_complex * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 8 * 64 * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += 512 * (int)sizeof(ap_float2);
+    W.off_ob = off; off += ap_align16(ob_complex * (int)sizeof(ap_float2));
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    int64_t g = W.n_groups < 512 ? W.n_groups : 512;      // persistent: two workgroups per CU
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
 // LDS geometry of the compile-time engine (shared with kernels_ct.h).  The first pass (radix R0)
 // leaves its output transposed with the odd row stride PQ = (nc / R0) | 1, so a frame needs

@@ -145,6 +145,17 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
             return ap_check_launch("ap_stft_f32(wave)");
         }
     }
+    if (n_fft == 1024) {
+        ApStftWave512Params W;
+        int grid = 0;
+        if (ap_prepare_stft_wave512(W, P, B, APHS_WAVES, APH_X_COMPLEX, APHS_OB_ROWS * APHS_OB_ROW, &grid) == AP_OK) {
+            rc = ap_allow_lds(ap_stft1024_wave_kernel, W.lds_bytes);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(ap_stft1024_wave_kernel, dim3(grid), dim3(64 * APHS_WAVES), W.lds_bytes,
+                               (hipStream_t)stream, W);
+            return ap_check_launch("ap_stft_f32(wave512)");
+        }
+    }
     {
         bool handled = false;
         rc = (P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? ap_launch_ct<0, 0>(P, n_fft, B, stream, &handled)

@@ -30,6 +30,71 @@
 #define APH_C16(r) ((float)__builtin_cos(6.283185307179586476925 * (r) / 16.0))
 #define APH_S16(r) ((float)__builtin_sin(6.283185307179586476925 * (r) / 16.0))
 
+// windowed samples v[j] = z[lane + 64 j] -> v[e] = Z[lane + 64 e] (three radix-8 passes, two
+// wave-private LDS transposes in X)
+AP_DEV void aph_forward(ap_float2 (&v)[8], ap_float2 *X, const ap_float2 *TW1, const ap_float2 *TW2, int lane) {
+    const int la = lane & 7, lb = lane >> 3;
+    {   // pass 1 over j, twiddle W_512^(l k1), transpose #1
+        ap_float2 t1[8];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t1[k] = TW1[k * 64 + lane];
+        ApButterfly<8>::run(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) X[APH_T1(8 * k + la) + lb] = v[k];
+    }
+    AP_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = X[APH_T1(lane) + i];                  // lane = (k1, a), register b
+    AP_WAVE_SYNC();
+    {   // pass 2 over b, twiddle W_64^(a c), transpose #2
+        ap_float2 t2[8];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) t2[c] = TW2[la * 8 + c];
+        ApButterfly<8>::run(v);
+#pragma unroll
+        for (int c = 1; c < 8; ++c) v[c] = ap_mul_fw(v[c], t2[c]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) X[APH_T2(c, lb) + la] = v[c];            // writer lane = (k1 = lb, a = la)
+    }
+    AP_WAVE_SYNC();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = X[APH_T2(lb, la) + i];                 // reader lane = (c = lb, k1 = la)
+    AP_WAVE_SYNC();
+    // pass 3 over a: this lane is (c = lb, k1 = la) and now holds Z[k1 + 8 c + 64 e] = Z[lane + 64 e]
+    ApButterfly<8>::run(v);
+}
+
+// paired real split of Z (v[e] = Z[lane + 64 e]): xk[r] = X[lane + 64 r], xm[r] = X[512 - lane - 64 r]
+// (CONJ = true) or its conjugate (enough for |X|), z256 = Z[256] (X[256] = conj Z[256]).  Only the
+// mirrored upper half goes through LDS (natural order in X[0..256)).
+template <bool CONJ>
+AP_DEV void aph_split(const ap_float2 (&v)[8], ap_float2 *X, ap_float2 tws0h, int lane, ap_float2 (&xk)[4],
+                      ap_float2 (&xm)[4], ap_float2 &z256) {
+#pragma unroll
+    for (int e = 4; e < 8; ++e) X[lane + 64 * (e - 4)] = v[e];                // Z[256 + lane + 64 (e-4)]
+    AP_WAVE_SYNC();
+    ap_float2 zm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int km = (APH_NC - (lane + 64 * r)) & (APH_NC - 1);             // mirror bin
+        zm[r] = km >= 256 ? X[km - 256] : v[0];                               // km = 0 only for lane 0, r = 0
+    }
+    z256 = X[0];
+    AP_WAVE_SYNC();
+    const ap_float2 half = ap_mk(0.5f, 0.5f), halfc = ap_mk(0.5f, -0.5f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const ap_float2 a = ap_add_conj(v[r], zm[r]);
+        const ap_float2 d = ap_sub_conj(v[r], zm[r]);
+        const ap_float2 w = r == 0 ? tws0h : ap_mul_bw_c(tws0h, APH_C16(r), APH_S16(r));
+        const ap_float2 u = ap_mul_fw(d, w);
+        xk[r] = ap_fma_add_mi(a, half, u);
+        xm[r] = CONJ ? ap_fma_sub_swap(a, halfc, u) : ap_fma_sub_mi(a, half, u);
+    }
+}
+
 struct ApMelWave512Params {
     const float *y;            // (B, L)
     const float *window;       // (1024)
@@ -73,9 +138,7 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
             for (int i = tid; i < P.n_parts; i += nt) part[i] = reinterpret_cast<const ap_int4 *>(P.parts)[i];
         }
     }
-    const int la = lane & 7, lb = lane >> 3;
     const ap_float2 tws0h = ap_scale(P.tw[lane], 0.5f);                      // W_1024^lane / 2
-    const ap_float2 half = ap_mk(0.5f, 0.5f);
     float *pp = reinterpret_cast<float *>(X);                                 // |X|^p plane, aliased on X
     ap_int4 mypart[APH_PASSES];
 #pragma unroll
@@ -155,70 +218,15 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
             AP_SCHED_FENCE();
             if (f + g + 1 < f_hi) next_frame(f + g + 1);
             AP_SCHED_FENCE();
-            // ---- pass 1 over j, twiddle, transpose #1 ------------------------------------------
+            aph_forward(v, X, TW1, TW2, lane);
             {
-                ap_float2 t1[8];
-#pragma unroll
-                for (int k = 1; k < 8; ++k) t1[k] = TW1[k * 64 + lane];
-                ApButterfly<8>::run(v);
-#pragma unroll
-                for (int k = 1; k < 8; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) X[APH_T1(8 * k + la) + lb] = v[k];
-            }
-            AP_WAVE_SYNC();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = X[APH_T1(lane) + i];          // lane = (k1, a), register b
-            AP_WAVE_SYNC();
-            // ---- pass 2 over b, twiddle W_64^(a c), transpose #2 -------------------------------
-            {
-                ap_float2 t2[8];
-#pragma unroll
-                for (int c = 1; c < 8; ++c) t2[c] = TW2[la * 8 + c];
-                ApButterfly<8>::run(v);
-#pragma unroll
-                for (int c = 1; c < 8; ++c) v[c] = ap_mul_fw(v[c], t2[c]);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) X[APH_T2(c, lb) + la] = v[c];    // writer lane = (k1 = lb, a = la)
-            }
-            AP_WAVE_SYNC();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = X[APH_T2(lb, la) + i];         // reader lane = (c = lb, k1 = la)
-            AP_WAVE_SYNC();
-            // ---- pass 3 over a: this lane is (c = lb, k1 = la) and now holds Z[k1 + 8 c + 64 e] =
-            //      Z[lane + 64 e], e = 0..7 ------------------------------------------------------
-            ApButterfly<8>::run(v);
-            const int kl = lane;
-            // ---- mirrored half through LDS (natural order, upper half only), paired split ----
-#pragma unroll
-            for (int e = 4; e < 8; ++e) X[kl + 64 * (e - 4)] = v[e];          // Z[256 + kl + 64 (e-4)]
-            AP_WAVE_SYNC();
-            ap_float2 zm[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int km = (APH_NC - (kl + 64 * r)) & (APH_NC - 1);       // mirror bin
-                zm[r] = km >= 256 ? X[km - 256] : v[0];                       // km = 0 only for kl = 0, r = 0
-            }
-            const ap_float2 z256 = X[0];                                      // Z[256] (lane 0 uses it)
-            AP_WAVE_SYNC();
-            {
-                float pk[4], pm[4];
+                ap_float2 xk[4], xm[4], z256;
+                aph_split<false>(v, X, tws0h, lane, xk, xm, z256);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const ap_float2 a = ap_add_conj(v[r], zm[r]);
-                    const ap_float2 d = ap_sub_conj(v[r], zm[r]);
-                    const ap_float2 w = r == 0 ? tws0h : ap_mul_bw_c(tws0h, APH_C16(r), APH_S16(r));
-                    const ap_float2 u = ap_mul_fw(d, w);
-                    const ap_float2 xk = ap_fma_add_mi(a, half, u);
-                    const ap_float2 xm = ap_fma_sub_mi(a, half, u);
-                    pk[r] = apw_pow2x<PMODE>(xk.x, xk.y, P.power);
-                    pm[r] = apw_pow2x<PMODE>(xm.x, xm.y, P.power);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int k = kl + 64 * r;
-                    pp[k] = pk[r];
-                    pp[APH_NC - k] = pm[r];
+                    const int k = lane + 64 * r;
+                    pp[k] = apw_pow2x<PMODE>(xk[r].x, xk[r].y, P.power);
+                    pp[APH_NC - k] = apw_pow2x<PMODE>(xm[r].x, xm[r].y, P.power);
                 }
                 if (lane == 0) pp[APH_NC / 2] = apw_pow2x<PMODE>(z256.x, z256.y, P.power);
             }
@@ -321,5 +329,150 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
             for (int i = 1; i < 64; ++i) m = fmaxf(m, partial[i]);
             ap_atomic_max_u32(P.max_key, ap_fkey(m));
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// STFT, n_fft = 1024, complex output (B, 513, T), constant padding.  The scheme of
+// ap_stft2048_wave_kernel (kernels_wave.h): the 8 waves of a workgroup transform 8 consecutive
+// frames, transpose through LDS (2 chunks of 257 bins, one buffer: a wave needs 5 KB here, so two
+// workgroups fit a CU and one stores while the other transforms) and write every row in
+// sector-aligned 8-frame windows with register carries along a contiguous stretch of groups.
+#define APHS_WAVES 8
+#define APHS_OB_ROW 9
+#define APHS_OB_ROWS 257
+
+struct ApStftWave512Params {
+    const float *y;            // (B, L)
+    const float *window;       // (1024)
+    const ap_float2 *tw;       // (1024)
+    ap_float2 *out;            // (B, 513, T)
+    int64_t L, T, groups_per_clip, n_groups;
+    int hop, pad;
+    int off_tw1, off_tw2, off_win, off_ob, lds_bytes;
+};
+
+__global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(ApStftWave512Params P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APH_X_COMPLEX;
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);
+    ap_float2 *OB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);        // [257][9]
+    {
+        const int nt = 64 * APHS_WAVES;
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        ap_float2 *win = reinterpret_cast<ap_float2 *>(ap_smem + P.off_win);
+        for (int i = tid; i < 8 * 64; i += nt) tw1[i] = P.tw[(2 * (i & 63) * (i >> 6)) & 1023];
+        if (tid < 64) tw2[tid] = P.tw[16 * (tid >> 3) * (tid & 7)];
+        for (int i = tid; i < APH_NC; i += nt) win[i] = reinterpret_cast<const ap_float2 *>(P.window)[i];
+    }
+    const ap_float2 tws0h = ap_scale(P.tw[lane], 0.5f);
+    AP_LDS_BARRIER();
+
+    const int F = APH_NC + 1;
+    const int sq = tid >> 3, sf = tid & 7;                                   // store role of this thread
+    const int T7 = (int)(P.T & 7), Ti = (int)P.T;
+    ap_float2 carry[2][2][2], carry_mid = ap_mk(0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) carry[c][rr][0] = carry[c][rr][1] = ap_mk(0.0f, 0.0f);
+    ap_float2 raw[8];
+    auto load_frame = [&](int64_t group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t = (group - b * P.groups_per_clip) * APHS_WAVES + wave;
+        const ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+        const int64_t base = t * (int64_t)P.hop - P.pad;
+        // frames beyond T read past the clip: zeros (never stored)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t p = base + 2 * (lane + 64 * j);
+            raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+        }
+    };
+    const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (g_lo < g_hi) load_frame(g_lo);
+
+    for (int64_t group = g_lo; group < g_hi; ++group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APHS_WAVES;
+        ap_float2 *ob = P.out + b * (int64_t)F * P.T + t0;
+        const int a0 = (int)(((reinterpret_cast<uintptr_t>(P.out) >> 3) + (uint64_t)(b * (int64_t)F * P.T + t0)) & 7);
+        const bool have_prev = group > g_lo && t0 > 0;
+        const bool last = group + 1 == g_hi || t0 + APHS_WAVES >= P.T;
+        const int trem = (int)(P.T - t0);
+
+        ap_float2 v[8];
+        {
+            ap_float2 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = WIN[lane + 64 * j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ap_mul2(raw[j], w[j]);
+        }
+        AP_SCHED_FENCE();
+        if (group + 1 < g_hi) load_frame(group + 1);
+        AP_SCHED_FENCE();
+        aph_forward(v, X, TW1, TW2, lane);
+        ap_float2 xk[4], xm[4], z256;
+        aph_split<true>(v, X, tws0h, lane, xk, xm, z256);
+
+        // ---- transposed store: chunk c holds r = 2c, 2c+1 (bins 64 r + lane and 512 - 64 r - lane) ----
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ap_float2 *buf = OB;
+            if (c > 0) AP_LDS_BARRIER();                                     // chunk 0 fully read
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * c + rr;
+                buf[(rr * 128 + lane) * APHS_OB_ROW + wave] = xk[r];
+                buf[(rr * 128 + 64 + lane) * APHS_OB_ROW + wave] = xm[r];
+            }
+            if (c == 1 && lane == 0) buf[256 * APHS_OB_ROW + wave] = ap_mk(z256.x, -z256.y);   // X[256] = conj Z[256]
+            AP_LDS_BARRIER();
+            int bins[5], slots[5], phi[5];
+            ap_float2 x[5];
+            const int ne = c == 1 ? 5 : 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * c + (i >> 1);
+                bins[i] = (i & 1) ? APH_NC - 64 * r - sq : 64 * r + sq;
+                slots[i] = (i >> 1) * 128 + (i & 1) * 64 + sq;
+            }
+            bins[4] = APH_NC / 2;
+            slots[4] = 256;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (i < ne) {
+                    phi[i] = (0 - (a0 + bins[i] * T7)) & 7;
+                    x[i] = buf[slots[i] * APHS_OB_ROW + ((sf + phi[i]) & 7)];
+                }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (i < ne) {
+                    ap_float2 &cy = i < 4 ? carry[c][i >> 1][i & 1] : carry_mid;
+                    const bool mine = i < 4 || tid < APHS_WAVES;
+                    const bool take = sf < 8 - phi[i];
+                    const int dt = phi[i] + sf - 8;
+                    const ap_float2 val = take ? cy : x[i];
+                    if (mine && (take ? have_prev : dt < trem)) ob[bins[i] * Ti + dt] = val;
+                    if (take) cy = x[i];
+                }
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    if (i < ne) {
+                        const bool mine = i < 4 || tid < APHS_WAVES;
+                        if (mine && sf < 8 - phi[i] && phi[i] + sf < trem) ob[bins[i] * Ti + phi[i] + sf] = x[i];
+                    }
+            }
+        }
+        AP_LDS_BARRIER();                                                    // OB free for the next group
     }
 }

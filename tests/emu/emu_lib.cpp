@@ -81,6 +81,15 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
             return AP_OK;
         }
     }
+    if (n_fft == 1024) {
+        ApStftWave512Params W;
+        int grid = 0;
+        if (ap_prepare_stft_wave512(W, P, B, APHS_WAVES, APH_X_COMPLEX, APHS_OB_ROWS * APHS_OB_ROW, &grid) == AP_OK) {
+            if (grid > 2) grid = 2;   // exercise the persistent group loop and the carries
+            emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_stft1024_wave_kernel(W); });
+            return AP_OK;
+        }
+    }
     if ((P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? emu_launch_ct<0, 0>(P, n_fft, B) : emu_launch_ct<0, 1>(P, n_fft, B))
         return AP_OK;
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });

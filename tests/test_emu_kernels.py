@@ -24,6 +24,9 @@ STFT_CASES = [
     # change inside a workgroup's stretch and a stretch that ends mid-clip
     (2048, 512, 10752, 3, "constant", True),
     (2048, 512, 9300, 2, "constant", False),
+    # n_fft = 1024 wave kernel: 3 clips x 22 frames (carries, clip change in a stretch), no centring
+    (1024, 256, 5376, 3, "constant", True),
+    (1024, 300, 6100, 2, "constant", False),
     (400, 160, 3000, 3, "constant", True),
     (64, 16, 500, 1, "edge", True),
     (30, 7, 400, 2, "constant", False),

@@ -65,6 +65,18 @@ def test_stft_2048_many_groups(B, L, pad_mode):
     np.testing.assert_allclose(host(S), R, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,L,hop,center", [(40, 44100, 256, True), (24, 60001, 300, True), (700, 9000, 256, False)])
+def test_stft_1024_many_groups(B, L, hop, center):
+    """n_fft=1024 wave kernel with more 8-frame groups than workgroups: carried sector-aligned row
+    windows, stretches that cross clip boundaries, odd and even frame counts."""
+    rng = np.random.default_rng(B + hop)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ap.stft(dev(y), n_fft=1024, hop_length=hop, center=center)
+    R = ao.stft(y, n_fft=1024, hop_length=hop, center=center)
+    assert S.shape == R.shape
+    np.testing.assert_allclose(host(S), R, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,L", [(40, 44100), (24, 60001), (300, 9000)])
 def test_istft_2048_many_groups(B, L):
     """n_fft=2048 irfft wave kernel with more groups than workgroups (carried sector-aligned row
