@@ -85,14 +85,14 @@ static inline int ap_prepare_resample_poly(const float *x, int64_t B, int64_t L,
 }
 
 // LDS-tiled decimator (up == 1): eligibility, output quad-groups per thread and dynamic LDS size.
-// Q = 1 measured fastest on MI355X (0.95 ms against 1.67 ms with Q = 4 for 1024 x 480 000 -> 160 000:
-// the bigger span leaves 3 workgroups per CU and the staging phase is no longer hidden).
+// Q = 2 / 1 measured 0.74 / 0.75 ms for 1024 x 480 000 -> 160 000 and Q = 4 slower (the bigger span
+// leaves 3 workgroups per CU and the staging phase is no longer hidden): start at 2.
 static inline bool ap_resample_decim_eligible(int up, int down, int n_taps, int *Q, int *lds_bytes) {
     if (up != 1 || down < 2 || down > 8) return false;
     const int R = 4;
     const int margin = down * (R - 1);
     const int steps = (n_taps + margin + 3) & ~3;
-    for (int q = 1; q >= 1; q >>= 1) {
+    for (int q = 2; q >= 1; q >>= 1) {
         const int span = AP_BLOCK * R * q * down + steps;
         const int bytes = (steps * R + span) * (int)sizeof(float);
         if (bytes <= 64 * 1024) { *Q = q; *lds_bytes = bytes; return true; }
