@@ -309,6 +309,43 @@ static inline int ap_prepare_stft_wave512(W512 &W, const ApStftParams &P, int64_
     return AP_OK;
 }
 
+// fused n_fft = 1024 ISTFT (kernels_wave512.h): returns 1 when it does not apply
+static inline bool ap_istft1024_fused_shape(int64_t B, int64_t T, int n_fft, int hop, int64_t out_offset) {
+    if (n_fft != 1024 || B <= 0 || T <= 0 || T > (1 << 20)) return false;
+    if (hop != 128 && hop != 256 && hop != 512) return false;
+    if (out_offset % 4 != 0) return false;
+    return ((T + 7) / 8) * B >= 64;
+}
+template <class W512>
+static inline int ap_prepare_istft_wave512(W512 &W, const float *S, const float *tw, int64_t B, int64_t T,
+                                           const float *window, int hop, int64_t out_offset, int64_t out_len,
+                                           float *y, int n_waves, int x_complex, int ib_complex, int *grid) {
+    if (!ap_istft1024_fused_shape(B, T, 1024, hop, out_offset)) return 1;
+    W.S = reinterpret_cast<const ap_float2 *>(S);
+    W.tw = reinterpret_cast<const ap_float2 *>(tw);
+    W.window = window;
+    W.y = y;
+    W.T = T;
+    W.groups_per_clip = (T + n_waves - 1) / n_waves;
+    W.n_groups = W.groups_per_clip * B;
+    W.out_offset = out_offset;
+    W.out_len = out_len;
+    W.hop = hop;
+    int off = n_waves * x_complex * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 8 * 64 * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += 1024 * (int)sizeof(float);
+    W.off_ib = off; off += ap_align16(ib_complex * (int)sizeof(ap_float2));
+    W.off_carry = off; off += 2 * (1024 - hop) * (int)sizeof(float);
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    int64_t g = W.n_groups / 4;                            // >= 4 groups per stretch
+    if (g > 512) g = 512;                                  // two workgroups per CU
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // compile-time specialised engine (kernels_ct.h): tile height and LDS bytes for complex length nc
 // LDS geometry of the compile-time engine (shared with kernels_ct.h).  The first pass (radix R0)
 // leaves its output transposed with the odd row stride PQ = (nc / R0) | 1, so a frame needs

@@ -259,7 +259,9 @@ int ap_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const f
 
 int64_t ap_istft_workspace_floats(int64_t B, int64_t T, int n_fft, int hop, int64_t out_offset) {
     if (B <= 0 || T <= 0 || n_fft <= 0) return 0;
-    return ap_istft_fused_shape(B, T, n_fft, hop, out_offset) ? 0 : B * T * (int64_t)n_fft;
+    if (ap_istft_fused_shape(B, T, n_fft, hop, out_offset)) return 0;
+    if (ap_istft1024_fused_shape(B, T, n_fft, hop, out_offset)) return 0;
+    return B * T * (int64_t)n_fft;
 }
 
 int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const float *window,
@@ -278,6 +280,18 @@ int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const
             hipLaunchKernelGGL(ap_irfft2048_wave_kernel<1>, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
                                (hipStream_t)stream, W);
             return ap_check_launch("ap_istft_f32(fused)");
+        }
+    }
+    if (n_fft == 1024 && S && tw && window && out && hop > 0 && out_len > 0) {
+        ApIstftWave512Params W;
+        int grid = 0;
+        if (ap_prepare_istft_wave512(W, S, tw, B, T, window, hop, out_offset, out_len, out, APHS_WAVES,
+                                     APH_X_COMPLEX, APHS_OB_ROWS * APHS_OB_ROW, &grid) == AP_OK) {
+            int rc0 = ap_allow_lds(ap_istft1024_wave_kernel, W.lds_bytes);
+            if (rc0 != AP_OK) return rc0;
+            hipLaunchKernelGGL(ap_istft1024_wave_kernel, dim3(grid), dim3(64 * APHS_WAVES), W.lds_bytes,
+                               (hipStream_t)stream, W);
+            return ap_check_launch("ap_istft_f32(fused 1024)");
         }
     }
     if (!frames_ws) AP_FAIL(AP_ERR_INVALID, "istft: NULL workspace");

@@ -476,3 +476,188 @@ __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(Ap
         AP_LDS_BARRIER();                                                    // OB free for the next group
     }
 }
+
+
+// ---------------------------------------------------------------------------------------
+// ISTFT, n_fft = 1024, hop 128 / 256 / 512: irfft of every frame + overlap-add in one kernel
+// (stft.py:292-338), the scheme of ap_irfft2048_wave_kernel<1>.  The 8 waves of a workgroup take 8
+// consecutive frames: the (bin, 8 frames) segments are staged through LDS (2 chunks of 257 bins,
+// next group's rows prefetched into registers), Hermitian merge at half scale, the mirrored half
+// exchanged through the wave's buffer, the 8 x 8 x 8 transform on conjugated data, then every wave
+// leaves its windowed frame in its buffer and the workgroup gathers the 8 hop positions the group
+// completes (<= n_fft / hop frames each, increasing frame order as overlap_add.metal:16-55),
+// divides by the window-sum-of-squares and stores; later positions go to an LDS carry (ping-pong)
+// for the next group of the workgroup's contiguous stretch.  A stretch that starts inside a clip
+// first runs the preceding group with its stores disabled.
+struct ApIstftWave512Params {
+    const ap_float2 *S;        // (B, 513, T)
+    const ap_float2 *tw;       // (1024)
+    const float *window;       // (1024) synthesis window
+    float *y;                  // (B, out_len)
+    int64_t T, groups_per_clip, n_groups, out_offset, out_len;
+    int hop;
+    int off_tw1, off_tw2, off_win, off_ib, off_carry, lds_bytes;
+};
+
+__global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_istft1024_wave_kernel(ApIstftWave512Params P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APH_X_COMPLEX;
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *WINP = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // (w[2n], w[2n+1])
+    const float *WIN = reinterpret_cast<const float *>(ap_smem + P.off_win);
+    ap_float2 *IB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ib);                  // [257][9]
+    {
+        const int nt = 64 * APHS_WAVES;
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
+        for (int i = tid; i < 8 * 64; i += nt) tw1[i] = P.tw[(2 * (i & 63) * (i >> 6)) & 1023];
+        if (tid < 64) tw2[tid] = P.tw[16 * (tid >> 3) * (tid & 7)];
+        for (int i = tid; i < 2 * APH_NC; i += nt) win[i] = P.window[i];
+    }
+    const ap_float2 tws0h = ap_scale(P.tw[lane], 0.5f);
+    const ap_float2 half = ap_mk(0.5f, 0.5f), halfc = ap_mk(0.5f, -0.5f);
+    AP_LDS_BARRIER();
+    const int F = APH_NC + 1;
+    const float scale = 1.0f / 512.0f;     // 1/n_fft, and the merge works at half scale
+    const int H = P.hop;
+    const int hs = H == 128 ? 7 : (H == 256 ? 8 : 9);
+    const int CN = 2 * APH_NC - H;                                   // carry length
+    const int Ti = (int)P.T;
+
+    const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    // thread (sq = tid / 8, sf = tid % 8) fetches frame sf of rows sq, 64 + sq, 128 + sq, 192 + sq of both
+    // chunks (bins 64 r + sq and 512 - 64 r - sq, r = 2c, 2c + 1), one group ahead, into registers
+    const int sq = tid >> 3, sf = tid & 7;
+    ap_float2 pre[2][4], pre_mid = ap_mk(0.0f, 0.0f);
+    auto load_group = [&](int64_t group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APHS_WAVES;
+        const bool live = t0 + sf < P.T;
+        const ap_float2 *sb = P.S + b * (int64_t)F * P.T + t0 + sf;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 2 * c + (i >> 1);
+                const int bin = (i & 1) ? APH_NC - 64 * r - sq : 64 * r + sq;
+                pre[c][i] = live ? sb[bin * Ti] : ap_mk(0.0f, 0.0f);
+            }
+        if (tid < APHS_WAVES) pre_mid = live ? sb[(APH_NC / 2) * Ti] : ap_mk(0.0f, 0.0f);
+    };
+    const int64_t g_first = (g_lo < g_hi && g_lo % P.groups_per_clip != 0) ? g_lo - 1 : g_lo;
+    if (g_first < g_hi) load_group(g_first);
+    for (int64_t group = g_first; group < g_hi; ++group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APHS_WAVES;
+
+        // ---- transpose through LDS: every wave collects its frame's bins in registers -------
+        ap_float2 xk[4], xm[4], xh = ap_mk(0.0f, 0.0f);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c > 0) AP_LDS_BARRIER();                             // chunk 0 fully read
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                IB[((i >> 1) * 128 + (i & 1) * 64 + sq) * APHS_OB_ROW + sf] = pre[c][i];
+            if (c == 1 && tid < APHS_WAVES) IB[256 * APHS_OB_ROW + sf] = pre_mid;
+            AP_LDS_BARRIER();
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                xk[2 * c + rr] = IB[(rr * 128 + lane) * APHS_OB_ROW + wave];
+                xm[2 * c + rr] = IB[(rr * 128 + 64 + lane) * APHS_OB_ROW + wave];
+            }
+            if (c == 1) xh = IB[256 * APHS_OB_ROW + wave];
+        }
+        AP_SCHED_FENCE();
+        if (group + 1 < g_hi) load_group(group + 1);
+        AP_SCHED_FENCE();
+        // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[512-k]) / 2 of the packed inverse -----
+        //   a = X[k] + conj X[512-k], d = X[k] - conj X[512-k], o = (W^-k / 2) d
+        //   conj Z[k] / 2 = conj(a/2 + i o),  conj Z[512-k] / 2 = a/2 - i o
+        ap_float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ap_float2 a_k = xk[r], a_m = xm[r];
+            if (r == 0 && lane == 0) { a_k.y = 0.0f; a_m.y = 0.0f; }      // DC / Nyquist imaginary parts ignored
+            const ap_float2 a = ap_add_conj(a_k, a_m);
+            const ap_float2 d = ap_sub_conj(a_k, a_m);
+            const ap_float2 w = r == 0 ? tws0h : ap_mul_bw_c(tws0h, APH_C16(r), APH_S16(r));
+            const ap_float2 o = ap_mul_bw(d, w);                           // W^-k = (c, +s)
+            v[r] = ap_fma_sub_swap(a, halfc, o);                            // index lane + 64 r
+            // index 512 - k belongs to the mirrored lane: upper half, natural order, through LDS
+            const int km = (APH_NC - (lane + 64 * r)) & (APH_NC - 1);
+            if (!(r == 0 && lane == 0)) X[km - 256] = ap_fma_add_mi(a, half, o);
+        }
+        if (lane == 0) X[0] = xh;           // bin 256 pairs with itself: conj Z[256] / 2 = X[256]
+        AP_WAVE_SYNC();
+#pragma unroll
+        for (int e = 4; e < 8; ++e) v[e] = X[lane + 64 * (e - 4)];
+        AP_WAVE_SYNC();
+        aph_forward(v, X, TW1, TW2, lane);
+        // y[n] = conj(Y[n]) / 1024 -> samples 2n, 2n+1 of the frame; n = lane + 64 e
+        float *carry_in = reinterpret_cast<float *>(ap_smem + P.off_carry) + (int)(group & 1) * CN;
+        float *carry_out = reinterpret_cast<float *>(ap_smem + P.off_carry) + (int)((group + 1) & 1) * CN;
+        {   // windowed frame -> this wave's exchange buffer, natural order
+            ap_float2 wv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wv[e] = WINP[lane + 64 * e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) X[lane + 64 * e] = ap_mul2(ap_mul2(v[e], ap_mk(scale, -scale)), wv[e]);
+        }
+        if (t0 == 0)
+            for (int i = tid; i < CN; i += 64 * APHS_WAVES) carry_in[i] = 0.0f;
+        AP_LDS_BARRIER();
+        const bool emit = group >= g_lo;
+        const bool clip_last = t0 + APHS_WAVES >= P.T;
+        const float *XF = reinterpret_cast<const float *>(ap_smem);   // frame f at XF + f * 2 APH_X_COMPLEX
+        const int n_own = APHS_WAVES * H;
+        const int64_t p0 = t0 * (int64_t)H;
+        const int t0i = (int)t0;
+        float *yb = P.y + b * P.out_len;
+        const int64_t n0 = p0 - P.out_offset;
+        for (int r = 4 * tid; r < n_own + CN; r += 4 * 64 * APHS_WAVES) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            if (r < CN) {
+                const ap_float4 c4 = *reinterpret_cast<const ap_float4 *>(carry_in + r);
+                s0 = c4.x; s1 = c4.y; s2 = c4.z; s3 = c4.w;
+            }
+            const int f_cov = ((r - 2 * APH_NC) >> hs) + 1;
+            const int f_lo = f_cov < 0 ? 0 : f_cov;
+            int f_hi = r >> hs;
+            if (f_hi > APHS_WAVES - 1) f_hi = APHS_WAVES - 1;
+            for (int f = f_lo; f <= f_hi; ++f) {
+                const ap_float4 q = *reinterpret_cast<const ap_float4 *>(XF + f * (2 * APH_X_COMPLEX) + (r - (f << hs)));
+                s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+            }
+            if (r >= n_own) {
+                ap_float4 c4; c4.x = s0; c4.y = s1; c4.z = s2; c4.w = s3;
+                *reinterpret_cast<ap_float4 *>(carry_out + (r - n_own)) = c4;
+            }
+            if (emit && (r < n_own || clip_last)) {
+                int F_lo = f_cov < -t0i ? -t0i : f_cov;
+                int F_hi = r >> hs;
+                if (F_hi > Ti - 1 - t0i) F_hi = Ti - 1 - t0i;
+                float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, w3 = 0.0f;
+                for (int Fi = F_lo; Fi <= F_hi; ++Fi) {
+                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (r - Fi * H));
+                    w0 += w.x * w.x; w1 += w.y * w.y; w2 += w.z * w.z; w3 += w.w * w.w;
+                }
+                const int64_t n = n0 + r;
+                if (n >= 0 && n < P.out_len) yb[n] = s0 / fmaxf(w0, 1e-8f);
+                if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
+                if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
+                if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+            }
+        }
+        if (emit && clip_last) {
+            int64_t n = p0 + n_own + CN - P.out_offset;
+            if (n < 0) n = 0;
+            for (n += tid; n < P.out_len; n += 64 * APHS_WAVES) yb[n] = 0.0f;
+        }
+        AP_LDS_BARRIER();                  // frames and staging buffer free for the next group
+    }
+}

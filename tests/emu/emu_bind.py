@@ -231,16 +231,21 @@ def dct(x, C, outer, n_in, inner, row_scale=None, db=None):
     return out
 
 
-def istft_fused(S, hop, window, out_len, out_offset=1024, grid_cap=0):
-    """ap_irfft2048_wave_kernel<1>: irfft + overlap-add of an n_fft = 2048 spectrum (B, 1025, T)."""
+def istft_fused(S, hop, window, out_len, out_offset=None, grid_cap=0):
+    """Fused irfft + overlap-add of an n_fft = 2048 (B, 1025, T) or n_fft = 1024 (B, 513, T) spectrum
+    (ap_irfft2048_wave_kernel<1> / ap_istft1024_wave_kernel)."""
     S = np.ascontiguousarray(S, np.complex64)
     B, F, T = S.shape
+    n_fft = 2 * (F - 1)
+    if out_offset is None:
+        out_offset = n_fft // 2
     Sv = np.ascontiguousarray(S.view(np.float32))
     out = np.zeros((B, out_len), np.float32)
     window = np.ascontiguousarray(window, np.float32)
-    tw = twiddles(2048)
-    _check(lib().emu_istft_fused_f32(_p(Sv), _i64(B), _i64(T), hop, _p(window), _p(tw), _i64(out_offset),
-                                     _i64(out_len), grid_cap, _p(out)))
+    tw = twiddles(n_fft)
+    fn = lib().emu_istft_fused_f32 if n_fft == 2048 else lib().emu_istft1024_fused_f32
+    _check(fn(_p(Sv), _i64(B), _i64(T), hop, _p(window), _p(tw), _i64(out_offset), _i64(out_len), grid_cap,
+              _p(out)))
     return out
 
 

@@ -198,6 +198,32 @@ int emu_gl_project_f32(int mode, const float *S, const float *angles, const floa
 }
 
 // fused irfft + overlap-add (n_fft = 2048); grid_cap > 0 limits the workgroups so stretches get long
+int emu_istft1024_fused_f32(const float *S, int64_t B, int64_t T, int hop, const float *window, const float *tw,
+                            int64_t out_offset, int64_t out_len, int grid_cap, float *out) {
+    ApIstftWave512Params W;
+    int grid = 0;
+    if (ap_prepare_istft_wave512(W, S, tw, B, T, window, hop, out_offset, out_len, out, APHS_WAVES, APH_X_COMPLEX,
+                                 APHS_OB_ROWS * APHS_OB_ROW, &grid) != AP_OK) {
+        // below the product's size threshold: run the fused kernel anyway for coverage
+        if ((hop != 128 && hop != 256 && hop != 512) || out_offset % 4 != 0) return AP_ERR_UNSUPPORTED;
+        W.S = reinterpret_cast<const ap_float2 *>(S); W.tw = reinterpret_cast<const ap_float2 *>(tw);
+        W.window = window; W.y = out; W.T = T;
+        W.groups_per_clip = (T + 7) / 8; W.n_groups = W.groups_per_clip * B;
+        W.out_offset = out_offset; W.out_len = out_len; W.hop = hop;
+        int off = APHS_WAVES * APH_X_COMPLEX * 8;
+        W.off_tw1 = off; off += 8 * 64 * 8;
+        W.off_tw2 = off; off += 64 * 8;
+        W.off_win = off; off += 1024 * 4;
+        W.off_ib = off; off += ap_align16(APHS_OB_ROWS * APHS_OB_ROW * 8);
+        W.off_carry = off; off += 2 * (1024 - hop) * 4;
+        W.lds_bytes = off;
+        grid = (int)(W.n_groups < 256 ? W.n_groups : 256);
+    }
+    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+    emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_istft1024_wave_kernel(W); });
+    return AP_OK;
+}
+
 int emu_istft_fused_f32(const float *S, int64_t B, int64_t T, int hop, const float *window, const float *tw,
                         int64_t out_offset, int64_t out_len, int grid_cap, float *out) {
     ApIrfftParams P;

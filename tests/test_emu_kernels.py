@@ -160,6 +160,20 @@ def test_emu_istft_fused(hop, L, B, grid_cap):
         np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=2048, length=length), atol=1e-5)
 
 
+@pytest.mark.parametrize("hop,L,B,grid_cap", [(256, 5376, 3, 2), (128, 4000, 2, 3), (512, 15000, 2, 2),
+                                              (256, 3000, 1, 0)])
+def test_emu_istft1024_fused(hop, L, B, grid_cap):
+    """Fused n_fft = 1024 ISTFT kernel: carries across groups, warm-up group of a stretch that starts
+    inside a clip, clip change inside a stretch, tail after the last group, shorter length."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ao.stft(y, n_fft=1024, hop_length=hop)
+    win = ao.padded_window("hann", 1024, 1024)
+    for length in (L, L - 300):
+        out = eb.istft_fused(S, hop, win, length, grid_cap=grid_cap)
+        np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=1024, length=length), atol=1e-5)
+
+
 def test_emu_irfft_ignores_dc_nyquist_imag():
     rng = np.random.default_rng(5)
     S = (rng.standard_normal((1, 33, 4)) + 1j * rng.standard_normal((1, 33, 4))).astype(np.complex64)

@@ -89,6 +89,28 @@ def test_istft_2048_many_groups(B, L):
     np.testing.assert_allclose(host(out)[:, 1024:-2048], y[:, 1024:-2048], atol=2e-5)
 
 
+@pytest.mark.parametrize("hop", [128, 256, 512])
+def test_istft_1024_fused_hops_and_lengths(hop):
+    """Fused n_fft=1024 ISTFT kernel (>= 64 groups): hop 128 / 256 / 512, natural length, a shorter one
+    and one beyond the last frame (zero tail), center on and off; then the round trip."""
+    rng = np.random.default_rng(hop + 1)
+    B, L = 24, 40000
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    for center in (True, False):
+        S = ao.stft(y, n_fft=1024, hop_length=hop, center=center)
+        Sd = dev(S.astype(np.complex64))
+        T = S.shape[-1]
+        end = (T - 1) * hop + 1024 - (512 if center else 0)
+        for length in (None, L - 1000, L + 3000):
+            got = host(ap.istft(Sd, hop_length=hop, center=center, length=length))
+            want = ao.istft(S, hop_length=hop, n_fft=1024, center=center, length=length)
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got[:, 128:end - 128], want[:, 128:end - 128], atol=2e-5)
+            assert not got[:, end:].any() and np.isfinite(got).all()
+    yr = host(ap.istft(ap.stft(dev(y), n_fft=1024, hop_length=hop), hop_length=hop, length=L))
+    np.testing.assert_allclose(yr[:, 512:-1024], y[:, 512:-1024], atol=2e-5)
+
+
 @pytest.mark.parametrize("hop", [256, 512, 1024])
 def test_istft_fused_hops_and_lengths(hop):
     """Fused irfft + overlap-add (n_fft=2048, >= 64 groups): hop 256 / 512 / 1024, natural length,
