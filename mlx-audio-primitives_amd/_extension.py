@@ -143,6 +143,46 @@ def lib():
     return _lib
 
 
+class _DeviceLib:
+    """The library with `device` made the current HIP device around every call.
+
+    hipLaunchKernelGGL, hipFuncSetAttribute (the > 48 KiB LDS opt-in) and hipMemsetD32Async act on
+    the process's CURRENT device, while the buffers and the stream handed over belong to the
+    tensors' device: without this guard a tensor on cuda:1 while cuda:0 is current would be
+    launched on the wrong device with a foreign stream handle."""
+
+    __slots__ = ("_index",)
+
+    def __init__(self, index: int):
+        self._index = index
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), name)
+        index = self._index
+
+        def call(*args):
+            import torch
+
+            if torch.cuda.current_device() == index:
+                return fn(*args)
+            with torch.cuda.device(index):
+                return fn(*args)
+
+        return call
+
+
+def dlib(device) -> _DeviceLib:
+    """`lib()` bound to `device` (a torch.device / index): every entry point that enqueues
+    device work is called through this."""
+    import torch
+
+    device = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    if device.type != "cuda":
+        raise RuntimeError(f"expected a HIP ('cuda') device, got {device}")
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    return _DeviceLib(index)
+
+
 def check(rc: int) -> None:
     """Turn a C status into the exception the reference would raise."""
     if rc == 0:
@@ -289,7 +329,7 @@ class _Ext:
         if output_length <= 0:
             raise ValueError("output_length must be positive")
         out = torch.empty((B, output_length), dtype=torch.float32, device=frames.device)
-        check(lib().ap_overlap_add_f32(ptr(frames), ptr(window), B, T, N, int(hop_length), 0,
+        check(dlib(frames.device).ap_overlap_add_f32(ptr(frames), ptr(window), B, T, N, int(hop_length), 0,
                                        int(output_length), ptr(out),
                                        self._stream(stream, frames.device)))
         return out
@@ -315,7 +355,7 @@ class _Ext:
             )
         T = 1 + (L - frame_length) // hop_length
         out = torch.empty((B, T, frame_length), dtype=torch.float32, device=signal.device)
-        check(lib().ap_frame_f32(ptr(signal), B, L, int(frame_length), int(hop_length), ptr(out),
+        check(dlib(signal.device).ap_frame_f32(ptr(signal), B, L, int(frame_length), int(hop_length), ptr(out),
                                  self._stream(stream, signal.device)))
         return out[0] if one_d else out
 
@@ -333,7 +373,7 @@ class _Ext:
             return signal                                      # pad_signal.cpp:149-151
         B, L = signal.shape
         out = torch.empty((B, L + 2 * pad_length), dtype=torch.float32, device=signal.device)
-        check(lib().ap_pad_f32(ptr(signal), B, L, int(pad_length), PAD_MODES[mode], ptr(out),
+        check(dlib(signal.device).ap_pad_f32(ptr(signal), B, L, int(pad_length), PAD_MODES[mode], ptr(out),
                                self._stream(stream, signal.device)))
         return out
 

@@ -26,13 +26,13 @@ def _to_db(S, ref, coefficient: float, amin: float, top_db):
     ref_value = 0.0
     if callable(ref):
         if ref in (torch.max, np.max, max) or getattr(ref, "__name__", "") in ("max", "amax"):
-            _x.check(_x.lib().ap_reduce_max_f32(_x.ptr(S), n, ws.data_ptr() + 4, _x.stream_ptr(dev)))
+            _x.check(_x.dlib(dev).ap_reduce_max_f32(_x.ptr(S), n, ws.data_ptr() + 4, _x.stream_ptr(dev)))
             ref_key = ws.data_ptr() + 4
         else:
             ref_value = float(ref(S))                         # arbitrary callable: host scalar
     else:
         ref_value = float(ref)
-    _x.check(_x.lib().ap_to_db_f32(_x.ptr(S), n, float(coefficient), float(amin), ref_value, ref_key,
+    _x.check(_x.dlib(dev).ap_to_db_f32(_x.ptr(S), n, float(coefficient), float(amin), ref_value, ref_key,
                                    -1.0 if top_db is None else float(top_db), _x.ptr(out),
                                    ws.data_ptr(), _x.stream_ptr(dev)))
     return out
@@ -53,7 +53,7 @@ def _from_db(S_db, ref: float, div: float):
     out = torch.empty_like(S_db)
     n = S_db.numel()
     if n:
-        _x.check(_x.lib().ap_from_db_f32(_x.ptr(S_db), n, float(ref), div, _x.ptr(out),
+        _x.check(_x.dlib(S_db.device).ap_from_db_f32(_x.ptr(S_db), n, float(ref), div, _x.ptr(out),
                                          _x.stream_ptr(S_db.device)))
     return out
 

@@ -200,6 +200,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     W.hopj = (P.hop == 256 || P.hop == 512 || P.hop == 1024) ? P.hop / 128 : 0;
     W.max_row_parts = desc[15];
     W.partial_stride = (W.n_slots + 1 + 3 + 3) & ~3;
+    if (W.partial_stride < 64) W.partial_stride = 64;          // the max reduction stages 64 lanes there
     W.rowstart = plan + desc[10];
     W.out = P.out_mel;
     W.max_key = nullptr;

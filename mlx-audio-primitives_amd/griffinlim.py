@@ -32,7 +32,7 @@ def _random_phase(random_state, shape, device) -> torch.Tensor:
     if n:
         st = np.random.default_rng(random_state).bit_generator.state["state"]
         m = (1 << 64) - 1
-        _x.check(_x.lib().ap_pcg64_uniform_f32(st["state"] >> 64, st["state"] & m, st["inc"] >> 64,
+        _x.check(_x.dlib(dev).ap_pcg64_uniform_f32(st["state"] >> 64, st["state"] & m, st["inc"] >> 64,
                                                st["inc"] & m, -np.pi, np.pi, n, _x.ptr(out),
                                                _x.stream_ptr(dev)))
     return out.reshape(shape)
@@ -41,7 +41,7 @@ def _random_phase(random_state, shape, device) -> torch.Tensor:
 def _project(mode, S, angles, R, momentum, tprev, rebuilt):
     B, F, T = S.shape
     TR = R.shape[-1] if R is not None else 0
-    _x.check(_x.lib().ap_gl_project_f32(
+    _x.check(_x.dlib(S.device).ap_gl_project_f32(
         mode, _x.ptr(S), None if angles is None else _x.ptr(angles),
         None if R is None else _x.ptr(torch.view_as_real(R)), TR, B * F, T, float(momentum),
         None if tprev is None else _x.ptr(torch.view_as_real(tprev)),
@@ -94,7 +94,7 @@ def griffinlim(S, n_iter: int = 32, hop_length: int | None = None, win_length: i
     n_ws = int(_x.lib().ap_istft_workspace_floats(B, T, int(n_fft), int(hop_length), pad))
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
     y = torch.empty((B, y_len), dtype=torch.float32, device=dev)
-    _x.check(_x.lib().ap_griffinlim_f32(
+    _x.check(_x.dlib(dev).ap_griffinlim_f32(
         _x.ptr(S), _x.ptr(angles), B, T, int(n_fft), int(hop_length), _x.ptr(win), _x.ptr(tw),
         int(bool(center)), _x.PAD_MODES[pad_mode], pad, y_len, TR, int(n_iter), float(momentum),
         _x.ptr(rebuilt), _x.ptr(tprev), _x.ptr(R), _x.ptr(ws), _x.ptr(y), _x.stream_ptr(dev)))

@@ -19,60 +19,64 @@ from ._validation import validate_non_negative, validate_positive
 from .stft import _frame_count, _get_padded_window, _get_twiddles, _resolve_stft_args
 from .windows import _default_device
 
-# Slaney mel scale constants (reference mel.py:24-28)
-_SLANEY_F_MIN = 0.0
-_SLANEY_F_SP = 200.0 / 3
-_SLANEY_MIN_LOG_HZ = 1000.0
-_SLANEY_MIN_LOG_MEL = (_SLANEY_MIN_LOG_HZ - _SLANEY_F_MIN) / _SLANEY_F_SP
-_SLANEY_LOGSTEP = np.log(6.4) / 27.0
+
+class _MelScale:
+    """The two mel scales the reference offers (mel.py:24-93), float64 on the host.
+
+    Slaney: linear below the 1 kHz knee (200/3 Hz per mel), logarithmic above it with
+    27 mels per factor 6.4; HTK: 2595 log10(1 + f/700)."""
+
+    knee_hz = 1000.0
+    hz_per_mel = 200.0 / 3
+    knee_mel = knee_hz / hz_per_mel
+    log_step = np.log(6.4) / 27.0
+
+    @classmethod
+    def forward(cls, hz: np.ndarray, htk: bool) -> np.ndarray:
+        if htk:
+            return 2595.0 * np.log10(1.0 + hz / 700.0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            above = cls.knee_mel + np.log(hz / cls.knee_hz) / cls.log_step
+        return np.where(hz < cls.knee_hz, (hz - 0.0) / cls.hz_per_mel, above)
+
+    @classmethod
+    def inverse(cls, mel: np.ndarray, htk: bool) -> np.ndarray:
+        if htk:
+            return 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+        above = cls.knee_hz * np.exp(cls.log_step * (mel - cls.knee_mel))
+        return np.where(mel < cls.knee_mel, 0.0 + cls.hz_per_mel * mel, above)
 
 
 def hz_to_mel(frequencies, htk: bool = False) -> np.ndarray:
     """Hz -> mel on the host (reference mel.py:31-62)."""
-    f = np.asarray(frequencies)
-    if htk:
-        return 2595.0 * np.log10(1.0 + f / 700.0)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        return np.where(
-            f < _SLANEY_MIN_LOG_HZ,
-            (f - _SLANEY_F_MIN) / _SLANEY_F_SP,
-            _SLANEY_MIN_LOG_MEL + np.log(f / _SLANEY_MIN_LOG_HZ) / _SLANEY_LOGSTEP,
-        )
+    return _MelScale.forward(np.asarray(frequencies), htk)
 
 
 def mel_to_hz(mels, htk: bool = False) -> np.ndarray:
     """mel -> Hz on the host (reference mel.py:65-93)."""
-    m = np.asarray(mels)
-    if htk:
-        return 700.0 * (10.0 ** (m / 2595.0) - 1.0)
-    return np.where(
-        m < _SLANEY_MIN_LOG_MEL,
-        _SLANEY_F_MIN + _SLANEY_F_SP * m,
-        _SLANEY_MIN_LOG_HZ * np.exp(_SLANEY_LOGSTEP * (m - _SLANEY_MIN_LOG_MEL)),
-    )
+    return _MelScale.inverse(np.asarray(mels), htk)
 
 
 @lru_cache(maxsize=64)
-def _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm):
-    """(bytes, shape) — reference mel.py:100-168."""
-    n_freqs = 1 + n_fft // 2
-    fft_freqs = np.linspace(0, sr / 2.0, n_freqs)
-    mel_points = np.linspace(hz_to_mel(fmin, htk=htk), hz_to_mel(fmax, htk=htk), n_mels + 2)
-    hz_points = mel_to_hz(mel_points, htk=htk)
-    f_lower = hz_points[:-2, np.newaxis]
-    f_center = hz_points[1:-1, np.newaxis]
-    f_upper = hz_points[2:, np.newaxis]
-    freqs = fft_freqs[np.newaxis, :]
-    # the reference's +1e-10 guards and float32 cast before normalising are kept
-    lower = (freqs - f_lower) / (f_center - f_lower + 1e-10)
-    upper = (f_upper - freqs) / (f_upper - f_center + 1e-10)
-    fb = np.maximum(0, np.minimum(lower, upper)).astype(np.float32)
-    if norm == "slaney":
-        enorm = 2.0 / (hz_points[2: n_mels + 2] - hz_points[:n_mels])
-        fb *= enorm[:, np.newaxis]
-    elif norm is not None:
+def _triangular_bank(sr, n_fft, n_mels, fmin, fmax, htk, norm) -> np.ndarray:
+    """Dense (n_mels, n_fft//2+1) float32 bank of triangles whose corners are equally spaced on
+    the mel scale.  Bit-compatible with the reference's NumPy builder (mel.py:100-168), whose
+    two quirks are part of the contract: each ramp's denominator carries a +1e-10 guard, and the
+    triangle is rounded to float32 BEFORE the Slaney area normalisation 2 / (f[i+2] - f[i])
+    (a float64 product rounded to float32 once more)."""
+    if norm not in ("slaney", None):
         raise ValueError(f"Unknown norm: '{norm}'. Supported: 'slaney', None")
-    return fb.tobytes(), fb.shape
+    corners = mel_to_hz(np.linspace(hz_to_mel(fmin, htk=htk), hz_to_mel(fmax, htk=htk), n_mels + 2),
+                        htk=htk)
+    left, peak, right = corners[:-2], corners[1:-1], corners[2:]
+    grid = np.linspace(0, sr / 2.0, 1 + n_fft // 2)[np.newaxis, :]
+    rising = (grid - left[:, np.newaxis]) / (peak - left + 1e-10)[:, np.newaxis]
+    falling = (right[:, np.newaxis] - grid) / (right - peak + 1e-10)[:, np.newaxis]
+    bank = np.maximum(0, np.minimum(rising, falling)).astype(np.float32)
+    if norm == "slaney":
+        np.multiply(bank, (2.0 / (right - left))[:, np.newaxis], out=bank, casting="same_kind")
+    bank.setflags(write=False)
+    return bank
 
 
 _device_filterbank_cache: dict[tuple, tuple] = {}
@@ -93,10 +97,9 @@ def _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, device):
     hit = _device_filterbank_cache.get(key)
     if hit is not None:
         return hit
-    fb_b, shape = _compute_mel_filterbank_np(sr, n_fft, n_mels, fmin, fmax, htk, norm)
-    fb_np = np.frombuffer(fb_b, dtype=np.float32).reshape(shape).copy()
+    fb_np = _triangular_bank(sr, n_fft, n_mels, fmin, fmax, htk, norm)
     plan_np, desc = _x.mel_plan_host(fb_np)
-    fb = torch.from_numpy(fb_np).to(dev)
+    fb = torch.from_numpy(fb_np.copy()).to(dev)
     plan = torch.from_numpy(plan_np).to(dev)
     _device_filterbank_cache[key] = (fb, plan, desc)
     return fb, plan, desc
@@ -133,7 +136,7 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
     out = torch.empty((B, n_mels, T), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
         tw = _get_twiddles(n_fft, dev)
-        _x.check(_x.lib().ap_melspec_max_f32(
+        _x.check(_x.dlib(dev).ap_melspec_max_f32(
             _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
             _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_mels),
             float(power), _x.ptr(out), None if _max_key is None else _max_key.data_ptr(),

@@ -48,7 +48,7 @@ def dct(x, type: int = 2, n: int | None = None, axis: int = -1, norm: str | None
     out = torch.empty(x.shape[:ax] + (int(n),) + x.shape[ax + 1:], dtype=torch.float32,
                       device=x.device)
     if out.numel():
-        _x.check(_x.lib().ap_dct_f32(_x.ptr(x), _x.ptr(C),
+        _x.check(_x.dlib(x.device).ap_dct_f32(_x.ptr(x), _x.ptr(C),
                                      None if _row_scale is None else _x.ptr(_row_scale), outer,
                                      int(n_in), inner, int(n), _x.ptr(out), _x.stream_ptr(x.device)))
     return out
@@ -108,7 +108,7 @@ def _db_dct(S: torch.Tensor, dct_type: int, n_mfcc: int, norm, lift, max_key=Non
     out = torch.empty((B, int(n_mfcc), inner), dtype=torch.float32, device=S.device)
     if out.numel():
         ws = max_key if max_key is not None else torch.empty(1, dtype=torch.int32, device=S.device)
-        _x.check(_x.lib().ap_db_dct_f32(_x.ptr(S), _x.ptr(C), None if lift is None else _x.ptr(lift),
+        _x.check(_x.dlib(S.device).ap_db_dct_f32(_x.ptr(S), _x.ptr(C), None if lift is None else _x.ptr(lift),
                                         B, int(n_in), inner, int(n_mfcc), 10.0, 1e-10, 1.0, None, 80.0,
                                         ws.data_ptr(), int(max_key is not None), _x.ptr(out),
                                         _x.stream_ptr(S.device)))

@@ -78,7 +78,7 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
     out = torch.empty((R, n_out), dtype=torch.float32, device=rows.device)
     if R > 0 and L > 0:
         taps, n_pre_remove = _poly_taps(up, down, rows.device)
-        _x.check(_x.lib().ap_resample_poly_f32(_x.ptr(rows), R, L, up, down, _x.ptr(taps),
+        _x.check(_x.dlib(rows.device).ap_resample_poly_f32(_x.ptr(rows), R, L, up, down, _x.ptr(taps),
                                                taps.numel(), n_pre_remove, n_out, _x.ptr(out),
                                                _x.stream_ptr(rows.device)))
     return _from_rows(out, lead, axis, ndim)
@@ -106,7 +106,7 @@ def _resample_fft(rows: torch.Tensor, out: torch.Tensor, post_scale: float) -> N
     legs = _cfft_split(L) + _cfft_split(n_out)
     tws = [_get_twiddles(n, dev) for n in legs]
     ws = torch.empty(4 * R * max(L, n_out), dtype=torch.float32, device=dev)
-    _x.check(_x.lib().ap_resample_fft_f32(_x.ptr(rows), R, L, n_out, _x.ptr(tws[0]), _x.ptr(tws[1]),
+    _x.check(_x.dlib(dev).ap_resample_fft_f32(_x.ptr(rows), R, L, n_out, _x.ptr(tws[0]), _x.ptr(tws[1]),
                                           _x.ptr(tws[2]), _x.ptr(tws[3]), _x.ptr(ws), _x.ptr(out),
                                           _x.stream_ptr(dev)))
     if post_scale != 1.0:
@@ -135,7 +135,7 @@ def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool =
             _resample_fft(rows, out, float(ratio) if scale else 1.0)
         return _from_rows(out, lead, axis, ndim)
     if R > 0 and n_out > 0:
-        _x.check(_x.lib().ap_resample_linear_f32(_x.ptr(rows), R, L, n_out,
+        _x.check(_x.dlib(rows.device).ap_resample_linear_f32(_x.ptr(rows), R, L, n_out,
                                                  float(ratio) if scale else 1.0, _x.ptr(out),
                                                  _x.stream_ptr(rows.device)))
     return _from_rows(out, lead, axis, ndim)

@@ -135,7 +135,7 @@ def stft(y, n_fft: int = 2048, hop_length: int | None = None, win_length: int | 
     out = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
         tw = _get_twiddles(n_fft, dev)
-        _x.check(_x.lib().ap_stft_f32(_x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win),
+        _x.check(_x.dlib(dev).ap_stft_f32(_x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win),
                                       _x.ptr(tw), int(bool(center)), _x.PAD_MODES[pad_mode], T,
                                       _x.ptr(out), _x.stream_ptr(dev)))
     else:
@@ -197,7 +197,7 @@ def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = N
             tgt = y
         else:
             tgt = torch.empty((B, ola_len), dtype=torch.float32, device=dev)
-        _x.check(_x.lib().ap_istft_f32(_x.ptr(Sr), B, T, int(n_fft), int(hop_length), _x.ptr(win),
+        _x.check(_x.dlib(dev).ap_istft_f32(_x.ptr(Sr), B, T, int(n_fft), int(hop_length), _x.ptr(win),
                                        _x.ptr(tw), _x.ptr(ws), offset, ola_len, _x.ptr(tgt),
                                        _x.stream_ptr(dev)))
         if tgt is not y:
@@ -224,17 +224,19 @@ def _complex_unary(S, fn_name: str) -> torch.Tensor:
     out = torch.empty(S.shape, dtype=torch.float32, device=dev)
     n = S.numel()
     if n:
-        _x.check(getattr(_x.lib(), fn_name)(_x.ptr(torch.view_as_real(S)), n, _x.ptr(out),
+        _x.check(getattr(_x.dlib(dev), fn_name)(_x.ptr(torch.view_as_real(S)), n, _x.ptr(out),
                                             _x.stream_ptr(dev)))
     return out
 
 
 def check_nola(window, hop_length: int, n_fft: int, tol: float = 1e-10) -> bool:
-    """Nonzero-overlap-add test on the host (reference stft.py:382-431)."""
-    win = get_window(window, n_fft, fftbins=True, device="cpu").numpy().astype(np.float64)
-    step = hop_length
-    n_bins = n_fft // step
-    binsums = sum(win[i * step:(i + 1) * step] ** 2 for i in range(n_bins))
-    if n_fft % step != 0:
-        binsums[: n_fft % step] += win[-(n_fft % step):] ** 2
-    return bool(np.min(binsums) > tol)
+    """Nonzero-overlap-add test on the host, in the window's own float32 like the reference
+    (stft.py:382-431, itself scipy.signal.check_NOLA): fold w**2 onto one hop — whole hops first,
+    then the ragged tail onto the leading positions — and require every folded position > tol."""
+    w2 = get_window(window, n_fft, fftbins=True, device="cpu").numpy() ** 2
+    whole, tail = divmod(n_fft, hop_length)
+    folded = np.add.reduce(w2[: whole * hop_length].reshape(whole, hop_length), axis=0) if whole \
+        else 0          # hop > n_fft: the reference fails on the same subscript (TypeError)
+    if tail:
+        folded[:tail] += w2[n_fft - tail:]
+    return bool(np.min(folded) > tol)
