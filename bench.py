@@ -10,8 +10,13 @@ rank owns its own batch, no data-path collective — SURVEY.md §8e):
               hann, center, constant pad, power 2, Slaney  -> T=431 frames/clip
 
 Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.
-For N>1 launch with torch.distributed.run (one rank per GPU, RCCL only for the
-barrier / max-over-ranks reduction of the timing).
+
+N > 1: one process per GPU.  Either the caller starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) or — plain `python bench.py --gpus N` — this process
+spawns the N ranks itself as fresh child processes BEFORE anything here touches the GPU, relays
+rank 0's JSON line and exits non-zero if any rank failed.  RCCL carries only the barrier and the
+MAX-over-ranks of the timing.
 """
 
 from __future__ import annotations
@@ -19,14 +24,13 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 WORKLOADS = {
     # name: (B per GPU, L, sr, n_fft, hop, n_mels)
@@ -34,12 +38,83 @@ WORKLOADS = {
     "whisper": (256, 160000, 16000, 400, 160, 80),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 N_ROTATE = 3                    # distinct input batches, rotated, so no step re-reads a
                                 # batch that is still in the 256 MiB Infinity Cache
 
 
+def parse_args(argv=None):
+    ap_ = argparse.ArgumentParser()
+    ap_.add_argument("--gpus", type=int, default=1)
+    ap_.add_argument("--steps", type=int, default=50)
+    ap_.add_argument("--warmup", type=int, default=5)
+    ap_.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap_.add_argument("--batch", type=int, default=None, help="clips per GPU (default: workload's)")
+    ap_.add_argument("--no-cpu-baseline", action="store_true")
+    ap_.add_argument("--stub-step", action="store_true",
+                     help="(tests) CPU ranks over gloo with a no-op step: exercises the launcher, the "
+                          "barrier / max-over-ranks timing and the JSON contract without a GPU; the "
+                          "line it prints is labelled and is not a measurement")
+    ap_.add_argument("--stub-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap_.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------
+# launcher: plain `python bench.py --gpus N` (no WORLD_SIZE) -> N fresh child ranks
+# ----------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str], timeout_s: float = 3000.0) -> int:
+    """Start n ranks of this script (one per GPU), wait for all, relay rank 0's stdout.
+
+    The parent never initialises the GPU (no HIP call, no torch.cuda.is_available()): the
+    children are ordinary fresh processes, nothing is exec'd over a process that holds a GPU
+    context.  Returns the exit code (0 only if every rank exited 0)."""
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + argv, env=env,
+            stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    out0 = ""
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.monotonic()))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:                    # a failed or hung rank must not leave the others behind
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    for rank, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f"bench.py: rank {rank} exited with {p.returncode}", file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode and p.returncode > 0 else 1)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------
+# workload
+# ----------------------------------------------------------------------------------------------
 def synth_batch(B, L, sr, seed, device):
     """Device-side version of benchmarks/utils.py:92-115: chirp + 0.1*N(0,1), per-clip noise."""
+    import numpy as np
+    import torch
+
     g = torch.Generator(device=device).manual_seed(seed)
     t = torch.linspace(0, L / sr, L, device=device, dtype=torch.float32)
     chirp = torch.sin(2 * np.pi * (100 + 2000 * t / 2) * t)
@@ -47,9 +122,14 @@ def synth_batch(B, L, sr, seed, device):
     return (chirp[None, :] + noise).contiguous()
 
 
-def cpu_baseline(sr, n_fft, hop, n_mels, L, budget_s=12.0):
-    """The oracle's melspectrogram arithmetic (float32 scipy.fft + BLAS) on the host
-    cores, on a bounded sample of the same workload."""
+def cpu_baseline(sr, n_fft, hop, n_mels, L, budget_s=10.0):
+    """CPU columns beside the GPU number, on a bounded sample of the same workload (rank 0, N=1):
+    `value` = the oracle's melspectrogram arithmetic (float32 scipy.fft + BLAS) on the host
+    cores ("port": librosa itself is not installed in this image);
+    `torch_stft_matmul` = torch.stft + |.|^2 + matmul on the same cores."""
+    import numpy as np
+    import torch
+
     from oracle import audio_oracle as ao
 
     # the 1-GPU box's CPU share is 16 cores even though os.cpu_count() reports the host
@@ -67,73 +147,132 @@ def cpu_baseline(sr, n_fft, hop, n_mels, L, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 2000:
             break
-    return {
+    rec = {
         "value": frames / el, "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": f"{reps} x {n_clips} clips x {L} samples ({frames} frames, {el:.1f} s); "
                   "oracle arithmetic with float32 scipy.fft.rfft(workers=cores) + BLAS matmul",
     }
+    # second column: torch.stft + matmul on the CPU (torch is the reference's own cross-check oracle,
+    # tests/test_torchaudio_crossval.py)
+    try:
+        torch.set_num_threads(cores)
+        yt = torch.from_numpy(y)
+        win = torch.from_numpy(ao.padded_window("hann", n_fft, n_fft))
+        fb = torch.from_numpy(ao.mel_filterbank(sr, n_fft, n_mels))
+
+        def tstep():
+            S = torch.stft(yt, n_fft, hop_length=hop, window=win, center=True, pad_mode="constant",
+                           return_complex=True)
+            return fb @ (S.real ** 2 + S.imag ** 2)
+
+        tstep()
+        tf, treps, t0 = 0, 0, time.perf_counter()
+        while True:
+            o = tstep()
+            tf += o.shape[0] * o.shape[2]
+            treps += 1
+            tel = time.perf_counter() - t0
+            if tel > budget_s / 2 or treps >= 2000:
+                break
+        rec["torch_stft_matmul"] = {"value": tf / tel, "unit": "frames/s", "cores": cores,
+                                    "sample": f"{treps} x {n_clips} clips ({tf} frames, {tel:.1f} s)"}
+    except Exception as e:  # pragma: no cover - the first column is the contract
+        rec["torch_stft_matmul"] = {"error": repr(e)}
+    return rec
 
 
-def main():
-    ap_ = argparse.ArgumentParser()
-    ap_.add_argument("--gpus", type=int, default=1)
-    ap_.add_argument("--steps", type=int, default=50)
-    ap_.add_argument("--warmup", type=int, default=5)
-    ap_.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap_.add_argument("--batch", type=int, default=None, help="clips per GPU (default: workload's)")
-    ap_.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap_.parse_args()
+def _traffic_record(workload):
+    """HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled
+    for 16-B/lane streaming reads as MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  Counters cannot
+    be collected from inside this process: the figure is the profile's, labelled as such."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        rec = json.load(open(tpath))
+    except Exception:
+        return None, None
+    src = rec.get("_source", {}).get(workload) or rec.get("_source", {}).get("default")
+    return rec.get(workload), src or "profiles/traffic_latest.json (rocprofv3 --pmc passes, not measured in this run)"
 
+
+def main(argv=None):
+    args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (nothing has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(
-            f"--gpus {args.gpus} needs one rank per GPU: launch with "
-            f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
+
+    import numpy as np  # noqa: F401
+    import torch
+
+    stub = args.stub_step
+    if stub:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=device)     # RCCL on ROCm
-
-    import mlx_audio_primitives_amd as ap
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)     # RCCL on ROCm
 
     B, L, sr, n_fft, hop, n_mels = WORKLOADS[args.workload]
     if args.batch:
         B = args.batch
-    batches = [synth_batch(B, L, sr, 42 + 1000 * rank + i, device) for i in range(N_ROTATE)]
     T = 1 + L // hop
 
-    def step(i):
-        return ap.melspectrogram(batches[i % N_ROTATE], sr=sr, n_fft=n_fft, hop_length=hop,
-                                 n_mels=n_mels)
+    if stub:
+        if rank == args.stub_fail_rank:
+            raise SystemExit(3)            # (tests) a rank that dies before the first barrier
 
-    out = step(0)
-    assert out.shape == (B, n_mels, T)
+        def step(i):
+            return None
+
+        def sync():
+            pass
+    else:
+        import mlx_audio_primitives_amd as ap
+
+        batches = [synth_batch(B, L, sr, 42 + 1000 * rank + i, device) for i in range(N_ROTATE)]
+
+        def step(i):
+            return ap.melspectrogram(batches[i % N_ROTATE], sr=sr, n_fft=n_fft, hop_length=hop,
+                                     n_mels=n_mels)
+
+        sync = torch.cuda.synchronize
+        out = step(0)
+        assert out.shape == (B, n_mels, T)
     for i in range(args.warmup):
-        out = step(i)
+        step(i)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    if not stub:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
-    ev0.record()          # torch's current stream == the stream the kernels are enqueued on
+    if not stub:
+        ev0.record()      # torch's current stream == the stream the kernels are enqueued on
     for i in range(args.steps):
-        out = step(i)
-    ev1.record()
+        step(i)
+    if not stub:
+        ev1.record()
     barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = ev0.elapsed_time(ev1) if not stub else wall * 1e3
 
     from mlx_audio_primitives_amd import sharding
     wall = sharding.max_over_ranks(wall, device=device)        # slowest rank decides
@@ -146,13 +285,12 @@ def main():
         launch_ms = dev_ms / args.steps
         alg_bytes = (4 * hop + 4 * n_mels) * B * T           # 4H + 4M per frame
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload)
-            except Exception:
-                traffic = None
+        frames_per_s_gpu = B * T / (launch_ms * 1e-3)
+        traffic, traffic_source = _traffic_record(args.workload)
+        F = n_fft // 2 + 1
+        # the other denominators SURVEY.md §8d asks to see beside HBM (frames/s one GPU could do if
+        # that resource were the only limit):
+        mfma_dense = F32_PEAK_TFLOPS * 1e12 / (2.0 * n_mels * F)      # dense f32 mel_basis @ |S|^2 on MFMA
         rec = {
             "metric": "mel-spectrogram frames/sec (n_fft=%d, n_mels=%d)" % (n_fft, n_mels),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -165,10 +303,22 @@ def main():
                        "clips_per_gpu": B, "frames_per_clip": T, "parallelism": f"clip-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": "fused mel (pad+frame+window+rfft+|.|^2+mel)",
-                         "kernel_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frames_per_s_per_gpu": frames_per_s_gpu,
+                         "other_bounds_frames_per_s": {
+                             "hbm": HBM_PEAK_GBS * 1e9 / (4 * hop + 4 * n_mels),
+                             "mfma_dense_f32": mfma_dense,
+                             "note": "mfma_dense_f32 = 157.3 TF / (2 M F) flop per frame: what a DENSE "
+                                     "f32-MFMA contraction would cap the fused pipeline at; this build "
+                                     "contracts the banded filterbank on the VALU instead (DESIGN.md 4.1)"},
+                         "frac_of_mfma_dense": frames_per_s_gpu / mfma_dense},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            rec["data"] = "stub (launcher test: no kernel ran, not a measurement)"
+            rec["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline and not stub:
             rec["cpu_baseline"] = cpu_baseline(sr, n_fft, hop, n_mels, L)
         print(json.dumps(rec), flush=True)
     if dist is not None:

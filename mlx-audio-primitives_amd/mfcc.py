@@ -59,10 +59,17 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
          center: bool = True, pad_mode: str = "constant", power: float = 2.0, n_mels: int = 128,
          fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
          mel_norm: str | None = "slaney", dct_type: int = 2, norm: str | None = "ortho",
-         lifter: int = 0) -> torch.Tensor:
+         lifter: int = 0, group=None, _max_reduce=None) -> torch.Tensor:
     """Mel-frequency cepstral coefficients (reference mfcc.py:143-287).
 
-    Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames)."""
+    Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames).
+
+    ``group`` (not in the reference, which is single-device): when the batch is sharded by clip
+    over the ranks of a torch.distributed process group, pass that group (or ``True`` for the
+    default group) and the max(S) that the dB stage clips against (global over the whole batch,
+    convert.py:58) is MAX-all-reduced — 4 bytes — between the mel kernel and the dB + DCT kernel,
+    so every rank produces exactly the rows the unsharded call would.  ``_max_reduce`` is the
+    same hook as a callable on the 1-element int32 key tensor (tests)."""
     validate_positive(n_mfcc, "n_mfcc")
     provided = S is not None
     max_key = None
@@ -76,6 +83,11 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
                            _max_key=max_key)
         if S.numel() == 0:
             max_key = None
+        elif _max_reduce is not None:
+            _max_reduce(max_key)
+        elif group is not None:
+            from .sharding import global_max_key
+            global_max_key(max_key, None if group is True else group)
     else:
         S = _x.to_device_f32(S)
     batched = S.ndim == 3

@@ -62,6 +62,23 @@ def global_max(local: torch.Tensor, group=None) -> torch.Tensor:
     return m[0]
 
 
+def global_max_key(key: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place MAX all-reduce of the 4-byte order-preserving key the mel / reduce kernels raise
+    for max(S) (csrc: ap_fkey — keys compare as UNSIGNED 32-bit integers, the tensor holding one
+    is int32).  This is the single cross-shard dependency of the path: a clip-sharded
+    ``mfcc`` / ``power_to_db(top_db=...)`` clips against the max of the WHOLE batch
+    (convert.py:58).  ``mfcc(..., group=g)`` calls it between the mel kernel and the dB + DCT
+    kernel; world_size 1 / no process group is a no-op."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return key
+    wide = key.to(torch.int64) & 0xFFFFFFFF                  # unsigned order in a signed dtype
+    dist.all_reduce(wide, op=dist.ReduceOp.MAX, group=group)
+    key.copy_(wide.to(torch.int32))                          # wraps back to the same 32 bits
+    return key
+
+
 def max_over_ranks(value: float, device=None, group=None) -> float:
     """MAX all-reduce of a host scalar (bench.py: slowest rank's time)."""
     import torch.distributed as dist

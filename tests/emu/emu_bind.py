@@ -124,6 +124,20 @@ def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, bande
     return out
 
 
+def mel_wave_geometry(fb, B=4, L=22050, hop=512):
+    """(partial_stride, lds_bytes, n_slots, grid) of the n_fft=2048 mel wave kernel, or None."""
+    fb = np.ascontiguousarray(fb, np.float32)
+    plan, desc = mel_plan(fb)
+    out = np.zeros(4, np.int32)
+    rc = lib().emu_mel_wave_geometry(_p(fb), plan.ctypes.data_as(_i32p), desc.ctypes.data_as(_i32p),
+                                     fb.shape[0], _i64(B), _i64(L), hop, out.ctypes.data_as(_i32p))
+    return None if rc == 1 else tuple(int(v) for v in out)
+
+
+def mel_wave_partial_stride(fb):
+    return mel_wave_geometry(fb)[0]
+
+
 def irfft_frames(S, n_fft):
     S = np.asarray(S)
     B, F, T = S.shape

@@ -141,6 +141,25 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
     return AP_OK;
 }
 
+// geometry the launch code derives for the n_fft = 2048 mel wave kernel: [0] partial_stride,
+// [1] lds_bytes, [2] n_slots, [3] grid; returns 1 when the kernel does not apply
+int emu_mel_wave_geometry(const float *fb, const int32_t *plan, const int32_t *desc, int n_mels,
+                          int64_t B, int64_t L, int hop, int32_t *out4) {
+    static float dummy[4];
+    ApStftParams P;
+    const int64_t T = ap_n_frames(L, 2048, hop, 1);
+    int rc = ap_prepare_stft(P, dummy, B, L, 2048, hop, dummy, dummy, 1, AP_PAD_CONSTANT, T);
+    if (rc != AP_OK) return rc;
+    rc = ap_prepare_mel(P, fb, plan, desc, n_mels, 2.0f, dummy);
+    if (rc != AP_OK) return rc;
+    if (!ap_mel_wave_eligible(2048, plan, desc)) return 1;
+    ApMelWaveParams W;
+    int grid = 0;
+    if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) != AP_OK) return 1;
+    out4[0] = W.partial_stride; out4[1] = W.lds_bytes; out4[2] = W.n_slots; out4[3] = grid;
+    return AP_OK;
+}
+
 int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const float *tw,
                          float *frames) {
     ApIrfftParams P;

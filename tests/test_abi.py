@@ -127,6 +127,21 @@ def test_check_nola_and_validation_messages():
         ap.validate_range(1.0, "momentum", min_val=0.0, max_val=1.0, max_inclusive=False)
 
 
+@pytest.mark.parametrize("window", ["hann", "hamming", "blackman", "bartlett", "rectangular"])
+def test_check_nola_matches_oracle_on_a_grid(window):
+    """stft.py:382-431 (scipy.signal.check_NOLA): hops that divide n_fft, ragged hops, hop = n_fft
+    (hann / bartlett / blackman start at 0 -> False), hop = 1, and array windows."""
+    for n_fft in (16, 64, 400, 512, 2048):
+        for hop in (1, 3, n_fft // 4, n_fft // 3, n_fft // 2, n_fft // 2 + 1, n_fft - 1, n_fft):
+            assert ap.check_nola(window, hop, n_fft) == ao.check_nola(window, hop, n_fft), (n_fft, hop)
+    w = ao.get_window(window, 64)
+    w[3::8] = 0.0                                   # position 3 of every 8-sample hop is never covered
+    for hop in (8, 16, 12, 64):
+        assert ap.check_nola(w, hop, 64) == ao.check_nola(w, hop, 64)
+    assert ap.check_nola(w, 8, 64) is False and ap.check_nola(w, 12, 64) is True
+    assert ap.check_nola(window, 16, 64, tol=1e3) == ao.check_nola(window, 16, 64, tol=1e3) is False
+
+
 def test_cpu_baseline_variant_matches_oracle():
     y = ao.random_signal(8000)
     a = ao.melspectrogram_cpu_baseline(y[None], workers=2)

@@ -97,6 +97,29 @@ def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
     assert amax == A.max()            # the key the kernel raises for mfcc's top_db clip
 
 
+@pytest.mark.parametrize("sr,M,kw", [
+    (22050, 20, dict(fmax=2000.0)),      # 34 partial-sum slots: fewer than the 64 lanes of the max reduction
+    (48000, 8, dict(fmax=1000.0)),       # 8 slots
+    (22050, 10, {}),                     # rows of up to 30 parts (max_row_parts > 4)
+    (22050, 136, {}),                    # rows beyond the two per lane
+    (22050, 160, dict(norm=None)),
+])
+def test_emu_wave_kernel_unusual_filterbanks(sr, M, kw):
+    """Branches of the n_fft=2048 mel kernel the default 128-filter bank never takes."""
+    rng = np.random.default_rng(M)
+    y = rng.standard_normal((2, 6000)).astype(np.float32)
+    win = ao.padded_window("hann", 2048, 2048)
+    fb = ao.mel_filterbank(sr, 2048, M, **kw)
+    A, amax = eb.melspec(y, 2048, 512, win, fb, return_max=True)
+    A0 = eb.melspec(y, 2048, 512, win, fb)
+    R = ao.melspectrogram(y, sr=sr, n_fft=2048, hop_length=512, n_mels=M, **kw)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(A, A0)
+    assert amax == A.max()
+    # every wave stages its 64 lane maxima in its own partial-sum region
+    assert eb.mel_wave_partial_stride(fb) >= 64
+
+
 @pytest.mark.parametrize("hop", [256, 1024, 500, 128])
 def test_emu_wave_kernel_hops(hop):
     """Frame-to-frame register reuse of the overlapping samples (hop 256 / 512 / 1024) against the

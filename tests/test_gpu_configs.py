@@ -1,0 +1,226 @@
+"""GPU parity at the BASELINE.json configurations that round 1 only timed, and for the branches of
+the fused kernels no earlier test reached:
+
+  * cfg4 end to end at batch: resample_poly 48k -> 16k, then mfcc13 / 128 mels with the GLOBAL
+    top_db clip (convert.py:58) biting because the clips' levels differ by 60-100 dB — this is
+    the path where max(S) comes out of the mel kernel (one atomic per wave over the whole grid);
+  * the cfg5 per-GPU shard shape, 512 clips x 480 000 samples (T = 3001), for the Whisper and the
+    headline mel parameters: oracle on a subsample of clips, and two size-independent properties
+    over the FULL output (power-of-two scaling is exact in binary floating point; a clip's
+    result does not depend on where it sits in the batch);
+  * Griffin-Lim at the fused n_fft = 2048 / hop 512 and n_fft = 1024 / hop 256 kernels against the
+    oracle, element by element, for 1-4 iterations, with momentum 0 and 0.99, init zeros,
+    and `length`s that make the re-analysis frame count differ from T (griffinlim.py:156-165);
+  * the headline kernel's rare branches: more than 128 filters, rows cut into more than 4 parts,
+    and the narrow-band filterbank whose partial-sum region is smaller than a wave (round-1
+    advisor finding: the max reduction staged 64 lanes there).
+"""
+
+import numpy as np
+import pytest
+
+from oracle import audio_oracle as ao
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import mlx_audio_primitives_amd as ap  # noqa: E402
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ cfg4
+def test_cfg4_resample_then_mfcc_batched_global_clip():
+    """BASELINE config 4 chain on 64 clips x 10 s @ 48 kHz.  Clip levels are spread over 100 dB
+    so that power_to_db's clip at (global max - 80 dB) cuts into most clips."""
+    B, L = 64, 480000
+    g = torch.Generator(device="cuda").manual_seed(44)
+    y = torch.randn((B, L), device="cuda", generator=g)
+    t = torch.linspace(0, 10.0, L, device="cuda")
+    y = y * 0.05 + torch.sin(2 * np.pi * (200 + 300 * t) * t)[None, :]
+    gains = torch.ones(B, device="cuda")
+    gains[5] = 1e3                  # +60 dB: the global max lives in this clip
+    gains[17] = 1e-2                # -40 dB: partly below the clip floor
+    gains[33] = 1e-3                # -60 dB: almost entirely clipped
+    gains[63] = 1e-5                # everything at the floor
+    y = (y * gains[:, None]).contiguous()
+
+    y16 = ap.resample_poly(y, 1, 3)
+    assert y16.shape == (B, 160000)
+    got = ap.mfcc(y16, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    assert got.shape == (B, 13, 313)
+
+    yh = host(y)
+    r_want = ao.resample_poly(yh, 1, 3)                                  # scipy.signal.resample_poly
+    np.testing.assert_array_equal(host(y16), r_want)                     # bit-exact leg
+    # the oracle sees the whole batch: its clip floor is the batch-global one
+    want = ao.mfcc(r_want, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    got = host(got)
+    # the clip really bites: clip 63 is a constant (floor) spectrum -> only c0 is non-zero
+    assert np.abs(want[63, 1:]).max() < 1e-3
+    S_db = ao.power_to_db(ao.melspectrogram(r_want[[5, 17, 33]], sr=16000, n_fft=2048, hop_length=512,
+                                            n_mels=128), top_db=None)
+    floor = S_db[0].max() - 80.0
+    assert (S_db[1] < floor).any() and (S_db[1] > floor).any()          # clip 17: cut in the middle
+    for b in (0, 5, 17, 33, 63, 40):
+        np.testing.assert_allclose(got[b], want[b], rtol=1e-4, atol=2e-3, err_msg=f"clip {b}")
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
+
+
+def test_mfcc_narrow_band_filterbank_batched_max():
+    """n_mels = 20, fmax = 2000 at n_fft = 2048: 34 partial-sum slots per frame, fewer than the 64
+    lanes the max reduction stages (kernels_wave.h max-key path).  B >= 8 so that
+    every wave of several workgroups runs it concurrently."""
+    rng = np.random.default_rng(20)
+    y = rng.standard_normal((12, 30000)).astype(np.float32)
+    y[3] *= 300.0
+    for kw in (dict(sr=22050, n_mels=20, fmax=2000.0), dict(sr=22050, n_mels=10, fmax=1000.0),
+               dict(sr=48000, n_mels=8, fmax=1000.0)):
+        S = host(ap.melspectrogram(dev(y), n_fft=2048, hop_length=512, **kw))
+        np.testing.assert_allclose(S, ao.melspectrogram(y, n_fft=2048, hop_length=512, **kw),
+                                   rtol=1e-4, atol=1e-4, err_msg=str(kw))
+        n_mfcc = min(13, kw["n_mels"])
+        got = host(ap.mfcc(dev(y), n_mfcc=n_mfcc, n_fft=2048, hop_length=512, **kw))
+        want = ao.mfcc(y, n_mfcc=n_mfcc, n_fft=2048, hop_length=512, **kw)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3, err_msg=str(kw))
+
+
+# ------------------------------------------------------------------ headline kernel, rare branches
+@pytest.mark.parametrize("n_mels,kw", [(136, {}), (160, {}), (10, {}), (4, {}), (200, {}),
+                                       (160, dict(power=1.0, pad_mode="reflect")),
+                                       (136, dict(hop_length=256, center=False))])
+def test_mel2048_many_filters_and_wide_rows(n_mels, kw):
+    """n_mels in {136, 160}: rows beyond the two per lane; n_mels in {10, 4}: rows of 30 / 48
+    parts (max_row_parts > 4); n_mels = 200 does not fit the wave kernel's LDS and runs on the
+    generic engine.  All against the oracle."""
+    rng = np.random.default_rng(n_mels)
+    y = rng.standard_normal((5, 20000)).astype(np.float32)
+    args = dict(sr=22050, n_fft=2048, hop_length=512, n_mels=n_mels)
+    args.update(kw)
+    got = host(ap.melspectrogram(dev(y), **args))
+    want = ao.melspectrogram(y, **args)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    if not kw:
+        n_mfcc = min(13, n_mels)
+        np.testing.assert_allclose(host(ap.mfcc(dev(y), n_mfcc=n_mfcc, **args)),
+                                   ao.mfcc(y, n_mfcc=n_mfcc, **args), rtol=1e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------ cfg5 shard
+@pytest.mark.parametrize("name,kw", [
+    ("whisper", dict(sr=16000, n_fft=400, hop_length=160, n_mels=80)),
+    ("headline", dict(sr=16000, n_fft=2048, hop_length=512, n_mels=128)),
+])
+def test_cfg5_per_gpu_shard(name, kw):
+    """512 clips x 30 s @ 16 kHz = one GPU's shard of BASELINE config 5 (983 MB in)."""
+    B, L = 512, 480000
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y = torch.randn((B, L), device="cuda", generator=g)
+    T = 1 + L // kw["hop_length"]
+    M = ap.melspectrogram(y, **kw)
+    assert M.shape == (B, kw["n_mels"], T)
+    assert bool(torch.isfinite(M).all())
+    # oracle on a subsample of clips: first, last, and some in the middle of worker stretches
+    idx = [0, 1, 77, 255, 256, 300, 511]
+    want = ao.melspectrogram(host(y[idx]), **kw)
+    np.testing.assert_allclose(host(M[idx]), want, rtol=1e-4, atol=1e-4)
+    # property 1 (full size): scaling by a power of two is exact, so mel(2 y) == 4 mel(y) bitwise
+    M2 = ap.melspectrogram(y * 2.0, **kw)
+    assert torch.equal(M2, M * 4.0)
+    del M2
+    # property 2 (full size): a clip's result does not depend on its place in the batch
+    # (different worker, different run boundaries, different neighbours)
+    perm = torch.randperm(B, device="cuda", generator=g)
+    Mp = ap.melspectrogram(y[perm].contiguous(), **kw)
+    assert torch.equal(Mp, M[perm])
+    # a checksum of the whole output, against the same sum taken clip by clip through 64-clip calls
+    parts = torch.cat([ap.melspectrogram(y[i:i + 64], **kw) for i in range(0, B, 64)])
+    assert torch.equal(parts, M)
+
+
+# ------------------------------------------------------------------ Griffin-Lim at the fused kernels
+def _gl_signal(L, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(L, dtype=np.float64) / 22050.0
+    y = np.sin(2 * np.pi * (150 + 900 * t) * t) + 0.5 * np.sin(2 * np.pi * 2500 * t)
+    return (y + 0.05 * rng.standard_normal(L)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256)])
+@pytest.mark.parametrize("momentum,init", [(0.99, "random"), (0.0, "random"), (0.99, "zeros"), (0.5, "zeros")])
+def test_griffinlim_fused_kernels_match_oracle(n_fft, hop, momentum, init):
+    """The fused irfft + overlap-add kernels, the wave STFT kernels and the ping-pong projection
+    (R / |R| in place of atan2 -> cos / sin) against ao.griffinlim element by element.  The
+    iteration is chaotic in the long run; over 1-4 steps the float32 paths still agree."""
+    L = 33000
+    y = np.stack([_gl_signal(L, 1), _gl_signal(L, 2)[::-1].copy()])
+    S = ao.magnitude(ao.stft(y, n_fft=n_fft, hop_length=hop))
+    Sd = dev(S)
+    for n_iter in (1, 2, 4):
+        got = host(ap.griffinlim(Sd, n_iter=n_iter, hop_length=hop, n_fft=n_fft, momentum=momentum,
+                                 init=init, random_state=42, length=L))
+        want = ao.griffinlim(S, n_iter=n_iter, hop_length=hop, n_fft=n_fft, momentum=momentum,
+                             init=init, random_state=42, length=L)
+        assert got.shape == want.shape == (2, L)
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-3,
+                                   err_msg=f"n_iter={n_iter} momentum={momentum} init={init}")
+
+
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (512, 128)])
+def test_griffinlim_length_changes_frame_count(n_fft, hop):
+    """`length` shorter / longer than the natural span: the re-analysis has fewer / more frames than
+    S and is zero-padded / cropped (griffinlim.py:156-165; the TR != T loop of ap_griffinlim_f32)."""
+    L = 30000
+    y = _gl_signal(L, 3)
+    S = ao.magnitude(ao.stft(y, n_fft=n_fft, hop_length=hop))
+    T = S.shape[-1]
+    for length in (L - 9 * hop - 17, L + 5 * hop + 3, None):
+        TR = T if length is None else 1 + length // hop
+        got = host(ap.griffinlim(dev(S), n_iter=3, hop_length=hop, n_fft=n_fft, random_state=11,
+                                 length=length))
+        want = ao.griffinlim(S, n_iter=3, hop_length=hop, n_fft=n_fft, random_state=11, length=length)
+        assert got.shape == want.shape
+        if length is not None:
+            assert TR != T and got.shape == (length,)
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=2e-3, err_msg=f"length={length}")
+
+
+def test_cfg3_roundtrip_batch64():
+    """BASELINE config 3, first half: stft -> istft(length=L) on 64 x 5 s, max-abs <= 1e-5
+    (README.md:118), through the fused ISTFT kernel."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = torch.rand((64, 110250), device="cuda", generator=g) * 2 - 1
+    S = ap.stft(y)
+    assert S.shape == (64, 1025, 216)
+    yr = ap.istft(S, length=110250)
+    assert float((yr - y).abs().max()) <= 1e-5
+
+
+def test_mfcc_clip_sharded_with_reduced_key_equals_unsharded():
+    """SURVEY §8e's one cross-shard dependency: with the max(S) key MAX-reduced across shards
+    (sharding.global_max_key does it over RCCL; here the hook is driven by hand for two shards in
+    one process) every shard reproduces the rows of the unsharded call bit for bit."""
+    rng = np.random.default_rng(8)
+    y = rng.standard_normal((8, 40000)).astype(np.float32)
+    y[6] *= 1e3                                   # the global max lives in the second shard
+    y[1] *= 1e-2
+    yd = dev(y)
+    kw = dict(sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    full = ap.mfcc(yd, **kw)
+    shards = [yd[:4].contiguous(), yd[4:].contiguous()]
+    keys = []
+    local = [ap.mfcc(s, _max_reduce=lambda k: keys.append(k.clone()), **kw) for s in shards]
+    assert not torch.equal(torch.cat(local), full)          # per-shard clip floors differ: the hook matters
+    wide = torch.stack([k.to(torch.int64) & 0xFFFFFFFF for k in keys]).max().to(torch.int32)
+    fixed = [ap.mfcc(s, _max_reduce=lambda k: k.fill_(wide), **kw) for s in shards]
+    assert torch.equal(torch.cat(fixed), full)
+    # world size 1: group=True is a no-op
+    assert torch.equal(ap.mfcc(yd, group=True, **kw), full)
+    np.testing.assert_allclose(host(full), ao.mfcc(y, **kw), rtol=1e-4, atol=2e-3)

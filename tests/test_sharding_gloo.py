@@ -72,6 +72,85 @@ def test_two_rank_shard_gather_and_global_clip(n_clips):
         assert slow == 2.0
 
 
+def _key(x: float) -> int:
+    """csrc ap_fkey: order-preserving unsigned key of a float, as the int32 the tensor stores."""
+    u = int(np.array([x], np.float32).view(np.uint32)[0])
+    k = (u | 0x80000000) if not (u & 0x80000000) else (~u & 0xFFFFFFFF)
+    return k - (1 << 32) if k >= (1 << 31) else k
+
+
+def _key_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mlx_audio_primitives_amd import sharding
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = []
+        # (rank 0 value, rank 1 value): positive keys are NEGATIVE int32s, so a signed MAX would
+        # pick the wrong rank in the mixed-sign case
+        for vals in ((3.0, 100.0), (250.5, 1e-7), (-2.0, -1.0), (-5.0, 0.25), (float("-inf"), 7.0)):
+            key = torch.tensor([_key(vals[rank])], dtype=torch.int32)
+            sharding.global_max_key(key)
+            res.append(int(key[0]))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_global_max_key_two_ranks():
+    """The 4-byte MAX all-reduce mfcc(group=...) puts between the mel kernel and the dB + DCT kernel."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_key_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [_key(v) for v in (100.0, 250.5, -1.0, 0.25, 7.0)]
+    for rank, res in results:
+        assert res == want, (rank, res, want)
+    # no process group: a no-op
+    from mlx_audio_primitives_amd import sharding
+    k = torch.tensor([_key(4.0)], dtype=torch.int32)
+    assert int(sharding.global_max_key(k)[0]) == _key(4.0)
+
+
+def _run_bench(*argv, timeout=600):
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run around it): the parent spawns the
+    two ranks, they rendezvous (gloo + a no-op step here; RCCL + the mel kernel on GPUs), rank 0's
+    single JSON line comes back through the parent, exit code 0."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]     # gloo logs its rendezvous on stdout
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["scaling"] == "weak" and rec["unit"] == "frames/s" and rec["higher_is_better"] is True
+    assert rec["config"]["parallelism"] == "clip-sharded x2"
+    assert rec["value"] > 0 and "stub" in rec["data"]
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-step", "--stub-fail-rank", "1",
+                   timeout=300)
+    assert r.returncode != 0
+    assert "rank 1 exited with 3" in r.stderr
+
+
 def test_shard_range_properties():
     from mlx_audio_primitives_amd.sharding import shard_range
 
