@@ -233,6 +233,65 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
     return AP_OK;
 }
 
+// n_fft = 2048 run kernel (kernels_mel2048.h): 12 waves per CU, output runs in registers.  Returns 1
+// when the shape is not one it serves (the caller then takes ap_mel2048_wave_kernel).
+//   n_waves / x_complex / partial_off: APM_WAVES, APW_X_COMPLEX, APM_PARTIAL_OFF of the kernel header
+static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, int64_t B, const int32_t *plan,
+                                     const int32_t *desc, int n_waves, int x_complex, int partial_off,
+                                     int *n_pass, int *grid) {
+    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (P.n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 1;
+    if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;          // 32-bit frame and sample arithmetic in the loop
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.parts = plan + desc[11];
+    W.n_parts = desc[12];
+    W.quads = reinterpret_cast<const float *>(plan + desc[13]);
+    W.n_quads = desc[14];
+    W.n_slots = desc[7];
+    W.hopj = P.hop == 512 ? 4 : 0;
+    W.max_row_parts = desc[15];
+    W.partial_stride = 0;
+    // partial sums live inside the wave's exchange buffer: slots + dump slot + 3 read-ahead, and the
+    // 64 lane maxima of the max reduction
+    if (partial_off + W.n_slots + 4 > 2 * x_complex || partial_off + 64 > 2 * x_complex) return 1;
+    W.rowstart = plan + desc[10];
+    W.out = P.out_mel;
+    W.max_key = nullptr;
+    W.L = P.L;
+    W.T = P.T;
+    W.tiles_per_clip = 0;
+    W.n_tiles = 0;
+    W.n_clips = B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    W.pad_mode = P.pad_mode;
+    W.n_mels = P.n_mels;
+    W.power = P.power;
+    const int pass = (W.n_parts + 63) / 64;
+    if (pass < 1 || pass > 4 || W.n_quads < 256 * pass) return 1;   // a pass reads 4 weight quads per lane
+    *n_pass = pass;
+    int off = n_waves * x_complex * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
+    W.off_wq = off; off += ap_align16(W.n_quads * 16);
+    W.off_parts = off;
+    W.off_partial = 0;
+    W.off_otile = 0;
+    W.otile_stride = 0;
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    // persistent: one 12-wave workgroup per CU, every wave a contiguous stretch of >= 8 frames
+    const int64_t n_frames = B * P.T;
+    int64_t g = (n_frames + (int64_t)n_waves * 8 - 1) / ((int64_t)n_waves * 8);
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // n_fft = 1024 wave-per-frame mel kernel (kernels_wave512.h): constant padding, plan with parts,
 // at most 128 filters (two rows per lane).  Returns 1 when it does not apply.
 struct ApMelWave512Params;

@@ -14,6 +14,7 @@
 #include "kernels_bigfft.h"
 #include "kernels_ct.h"
 #include "kernels_wave512.h"
+#include "kernels_mel2048.h"
 
 static thread_local char g_err[512] = "";
 
@@ -45,6 +46,24 @@ static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) 
     hipLaunchKernelGGL((ap_mel2048_wave_kernel<PMODE, PADGEN>), dim3(grid), dim3(64 * APW_WAVES), W.lds_bytes,
                        (hipStream_t)stream, W);
     return ap_check_launch("ap_melspec_f32(wave)");
+}
+
+// n_fft = 2048 run kernel (kernels_mel2048.h)
+template <int PMODE, int NW>
+static int ap_launch_mel_run(const ApMelWaveParams &W, int n_pass, int grid, void *stream) {
+#define AP_RUN_LAUNCH(NP)                                                                        \
+    do {                                                                                         \
+        int rc = ap_allow_lds(ap_mel2048_run_kernel<PMODE, NP, NW>, W.lds_bytes);                \
+        if (rc != AP_OK) return rc;                                                              \
+        hipLaunchKernelGGL((ap_mel2048_run_kernel<PMODE, NP, NW>), dim3(grid), dim3(64 * NW),    \
+                           W.lds_bytes, (hipStream_t)stream, W);                                 \
+    } while (0)
+    if (n_pass == 1) AP_RUN_LAUNCH(1);
+    else if (n_pass == 2) AP_RUN_LAUNCH(2);
+    else if (n_pass == 3) AP_RUN_LAUNCH(3);
+    else AP_RUN_LAUNCH(4);
+#undef AP_RUN_LAUNCH
+    return ap_check_launch("ap_melspec_f32(run)");
 }
 
 static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
@@ -188,7 +207,24 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
     if (rc != AP_OK) return rc;
     if (ap_mel_wave_eligible(n_fft, plan, desc)) {
         ApMelWaveParams W;
-        int grid = 0;
+        int grid = 0, n_pass = 0;
+        // power 2 / 1 with constant padding and <= 128 filters: the 12-wave run kernel
+        // (AP_MEL2048_WAVE=1 keeps the 8-wave tile kernel for A/B timing)
+        static const bool force_wave = std::getenv("AP_MEL2048_WAVE") != nullptr;
+        static const int run_waves = std::getenv("AP_MEL2048_RUN8") ? 8 : APM_WAVES;     // (experiment switch)
+        if (!force_wave && (power == 2.0f || power == 1.0f) &&
+            ap_prepare_mel_run(W, P, B, plan, desc, run_waves, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
+            if (max_key_dev) {
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+                if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+                W.max_key = max_key_dev;
+            }
+            if (run_waves == 8)
+                return power == 2.0f ? ap_launch_mel_run<2, 8>(W, n_pass, grid, stream)
+                                     : ap_launch_mel_run<1, 8>(W, n_pass, grid, stream);
+            return power == 2.0f ? ap_launch_mel_run<2, APM_WAVES>(W, n_pass, grid, stream)
+                                 : ap_launch_mel_run<1, APM_WAVES>(W, n_pass, grid, stream);
+        }
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
             if (max_key_dev) {            // the kernel raises the key itself: one atomic per wave
                 hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);

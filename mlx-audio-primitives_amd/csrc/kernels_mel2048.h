@@ -1,0 +1,347 @@
+// Fused mel-spectrogram for n_fft = 2048, the run kernel: 12 independent waves per CU, each wave
+// one frame at a time in registers + its own LDS exchange buffer, output runs in registers.
+//
+// Same transform and contraction as ap_mel2048_wave_kernel (kernels_wave.h: 16 x 16 x 4 complex
+// transform of the packed frame, paired real split, |X|^p plane, plan-based banded contraction),
+// re-cut around what rocprofv3 showed that kernel waiting for (profiles/README.md): with 8 waves
+// per CU a wave issues one instruction every 4-5 cycles whatever its kind, the frame loop carried
+// ~1000 of them (a 64-bit division per frame for (clip, frame), a branch ladder over the hop
+// variants, exec-mask juggling for rows >= n_mels, 64 v_mov_b32_dpp + 64 packed ops for a radix-4
+// that needs 64 + 48), and the LDS pipe and the VALUs were each ~60-65 % busy.  So:
+//
+//   * everything frame-invariant is a template parameter or a register: number of contraction
+//     passes (NPASS), (clip, frame) advanced incrementally, part descriptors as
+//     ready-made LDS addresses, rows >= n_mels computed like the others and simply not stored;
+//   * the quad radix-4 runs on v_fmac_f32_dpp: the DPP operand feeds the FMA directly
+//     (h += c * quad_perm(h)), the two per-lane signs are folded into the W_64 twiddles that
+//     precede it and the -i of lane 3 is two v_cndmask;
+//   * the 8-frame output run of a lane's two mel rows lives in registers (32 contiguous bytes per
+//     row and lane, as in ap_mel1024_wave_kernel): no output tile in LDS, and the partial sums
+//     alias the idle upper half of the wave's exchange buffer -> 10 KB of LDS per wave,
+//     12 waves + all tables = 152 KB per CU, <= 168 VGPRs: three waves per SIMD.
+//
+// Serves constant padding / center=False, n_mels <= 128, plans of <= 256 entries whose rows have
+// <= 4 parts; everything else stays on ap_mel2048_wave_kernel.  Reference: mel.py:245-352.
+#pragma once
+#include "kernels_wave.h"
+
+#define APM_WAVES 12          // waves per workgroup (3 per SIMD)
+#define APM_RUN 8             // frames per output run held in registers
+#define APM_PARTIAL_OFF 1152  // float offset of the partial sums inside the wave's X buffer (plane: 1025 floats)
+
+// per-lane constants of the transform (on top of ApwLane)
+struct ApmLane {
+    float c1, c2;        // stage coefficients of the quad radix-4: -s1, -s2
+    float sg;            // s1 s2: folded into the W_64^(a c) twiddles (and into v[0])
+    bool rot;            // lane 3 of the quad: multiply by -i between the stages
+};
+
+AP_DEV ApmLane apm_lane_init(int lane) {
+    ApmLane m;
+    const int qa = lane & 3;
+    const float s1 = qa < 2 ? 1.0f : -1.0f, s2 = (qa & 1) ? -1.0f : 1.0f;
+    m.c1 = -s1;
+    m.c2 = -s2;
+    m.sg = s1 * s2;
+    m.rot = qa == 3;
+    return m;
+}
+
+// Radix-4 across the quad on values held as h = (s1 s2) v, 8 complex values per call:
+//   stage 1: r = h - s1 h[lane ^ 2]         (= s2 (s1 v + v[lane ^ 2]))
+//   lane 3:  r *= -i                        (x, y) -> (y, -x)
+//   stage 2: out = r - s2 r[lane ^ 1]       (= s2 r' + r'[lane ^ 1] for the unsigned r')
+// outputs in bit-reversed lanes as in apw_forward.
+#ifdef AP_HOST_EMU
+AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
+    for (int i = 0; i < 8; ++i) {
+        x[i] = x[i] + m.c1 * ap_quad_xor2(x[i]);
+        y[i] = y[i] + m.c1 * ap_quad_xor2(y[i]);
+    }
+    for (int i = 0; i < 8; ++i) {
+        const float rx = x[i], ry = y[i];
+        x[i] = m.rot ? ry : rx;
+        y[i] = m.rot ? -rx : ry;
+    }
+    for (int i = 0; i < 8; ++i) {
+        x[i] = x[i] + m.c2 * ap_quad_xor1(x[i]);
+        y[i] = y[i] + m.c2 * ap_quad_xor1(y[i]);
+    }
+}
+#else
+// One asm block: v_fmac_f32_dpp takes the quad-permuted operand straight into the FMA
+// (d += c * d[lane ^ 2]); the compiler neither folds a DPP move into a VOP2 FMA here nor knows
+// about the DPP read inside an asm, so the block orders its instructions itself: `s_nop 1` covers
+// the 2 wait states between an outside VALU write and the first DPP read of that register, and
+// inside every DPP read sits >= 14 instructions behind the write of its register.
+#define APM_S1(i) "v_fmac_f32_dpp %" #i ", %" #i ", %17 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+#define APM_S2(i) "v_fmac_f32_dpp %" #i ", %" #i ", %18 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define APM_ROT(ix, iy)                                  \
+    "v_mov_b32 %16, %" #ix "\n\t"                       \
+    "v_cndmask_b32 %" #ix ", %" #ix ", %" #iy ", %19\n\t" \
+    "v_cndmask_b32 %" #iy ", %" #iy ", -%16, %19\n\t"
+AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
+    float t;
+    const unsigned long long rot_mask = 0x8888888888888888ull;      // lane 3 of every quad
+    asm volatile(
+        "s_nop 1\n\t"
+        APM_S1(0) APM_S1(1) APM_S1(2) APM_S1(3) APM_S1(4) APM_S1(5) APM_S1(6) APM_S1(7)
+        APM_S1(8) APM_S1(9) APM_S1(10) APM_S1(11) APM_S1(12) APM_S1(13) APM_S1(14) APM_S1(15)
+        APM_ROT(0, 1) APM_ROT(2, 3) APM_ROT(4, 5) APM_ROT(6, 7)
+        APM_ROT(8, 9) APM_ROT(10, 11) APM_ROT(12, 13) APM_ROT(14, 15)
+        APM_S2(0) APM_S2(1) APM_S2(2) APM_S2(3) APM_S2(4) APM_S2(5) APM_S2(6) APM_S2(7)
+        APM_S2(8) APM_S2(9) APM_S2(10) APM_S2(11) APM_S2(12) APM_S2(13) APM_S2(14) APM_S2(15)
+        : "+v"(x[0]), "+v"(y[0]), "+v"(x[1]), "+v"(y[1]), "+v"(x[2]), "+v"(y[2]), "+v"(x[3]), "+v"(y[3]),
+          "+v"(x[4]), "+v"(y[4]), "+v"(x[5]), "+v"(y[5]), "+v"(x[6]), "+v"(y[6]), "+v"(x[7]), "+v"(y[7]),
+          "=&v"(t)
+        : "v"(m.c1), "v"(m.c2), "s"(rot_mask));
+}
+#undef APM_S1
+#undef APM_S2
+#undef APM_ROT
+#endif
+
+AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
+#pragma unroll
+    for (int h = 0; h < 16; h += 8) {
+        float x[8], y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { x[i] = v[h + i].x; y[i] = v[h + i].y; }
+        apm_quad8(x, y, m);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[h + i] = ap_mk(x[i], y[i]);
+    }
+}
+
+// forward transform of apw_forward with the fmac-DPP quad stage; tw2s holds sg * W_64^(a c)
+AP_DEV void apm_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ap_float2 *tw2row,
+                        const ApwLane &c, const ApmLane &m) {
+    const int lane = c.lane;
+    {
+        ap_float2 t1[16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];
+        ApButterfly<16>::run(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
+    }
+    {
+        const int a = lane & 3, bq = lane >> 2;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) X[APW_T1(k * 4 + a) + bq] = v[k];
+    }
+    AP_WAVE_SYNC();
+    ap_float2 t2[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = X[APW_T1(lane) + i];
+#pragma unroll
+    for (int cc = 1; cc < 16; ++cc) t2[cc] = tw2row[cc];
+    AP_WAVE_SYNC();
+    ApButterfly<16>::run(v);
+    v[0] = ap_scale(v[0], m.sg);
+#pragma unroll
+    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);
+    apm_quad_radix4(v, m);
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) X[apw_zidx(c.k1p + 16 * cc + 256 * c.qd)] = v[cc];
+    AP_WAVE_SYNC();
+}
+
+template <int PMODE, int NPASS, int NW = APM_WAVES>
+__global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWaveParams P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
+    ap_float2 *TW2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);               // [4][17], signed
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);   // [16][64]
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // [1024] pairs
+    const ap_float4 *WQ = reinterpret_cast<const ap_float4 *>(ap_smem + P.off_wq);     // [n_quads]
+    float *pp = reinterpret_cast<float *>(X);                 // |X|^p plane of this wave (floats 0..1024)
+    float *partial = pp + APM_PARTIAL_OFF;                    // partial sums: idle part of X during the contraction
+    const int M = P.n_mels;
+
+    // ---------------- workgroup tables in LDS (once; the only workgroup barrier) ------
+    {
+        const int nt = 64 * NW;
+        ap_float4 *wq = reinterpret_cast<ap_float4 *>(ap_smem + P.off_wq);
+        for (int i = tid; i < P.n_quads; i += nt) wq[i] = reinterpret_cast<const ap_float4 *>(P.quads)[i];
+        apw_fill_tables(TW2, reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
+                        reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid, nt);
+    }
+    AP_LDS_BARRIER();
+    if (tid < 64) {       // fold the quad stage's signs s1 s2 of row a = tid >> 4 into its twiddles
+        const int a = tid >> 4;
+        const float sg = (a == 1 || a == 2) ? -1.0f : 1.0f;
+        TW2[a * 17 + (tid & 15)] = ap_scale(TW2[a * 17 + (tid & 15)], sg);
+    }
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    const ApmLane lm = apm_lane_init(lane);
+    // frame-invariant contraction state: LDS addresses of this lane's entries
+    const ap_float4 *pqa[NPASS], *pqb[NPASS];
+    float *sa[NPASS], *sb[NPASS];
+    float fz[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int pi = lane + 64 * ps;
+        ap_int4 pd;
+        pd.x = P.n_slots; pd.y = 0; pd.z = P.n_slots; pd.w = 0;          // idle entry: zero weights, dump slot
+        if (pi < P.n_parts) pd = reinterpret_cast<const ap_int4 *>(P.parts)[pi];
+        pqa[ps] = reinterpret_cast<const ap_float4 *>(pp) + pd.y;
+        pqb[ps] = reinterpret_cast<const ap_float4 *>(pp) + pd.w;
+        sa[ps] = partial + pd.x;
+        sb[ps] = partial + (pd.z < 0 ? P.n_slots : pd.z);
+        fz[ps] = pd.z < 0 ? 1.0f : 0.0f;                                  // one long part: both halves to slot A
+    }
+    int rs0[2], cnt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = lane + 64 * i;
+        rs0[i] = row < M ? P.rowstart[row] : 0;
+        cnt[i] = row < M ? P.rowstart[row + 1] - rs0[i] : 0;
+    }
+    AP_LDS_BARRIER();
+
+    const int64_t worker = (int64_t)blockIdx.x * NW + wave;
+    const int64_t n_workers = (int64_t)gridDim.x * NW;
+    const int64_t n_frames = P.n_clips * P.T;
+    const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
+    const int Ti = (int)P.T;
+    float vmax = -INFINITY;
+    if (f_lo < f_hi) {
+        int64_t b = f_lo / P.T;                   // the only division: (clip, frame) advance incrementally
+        int t = (int)(f_lo - b * P.T);
+        ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+        ap_float2 raw[16];
+        auto load_frame = [&](int tt) {
+            const int base = tt * P.hop - P.pad;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = base + 2 * (lane + 64 * j);
+                raw[j] = ap_clip_load2(clip, p);
+            }
+        };
+        load_frame(t);
+        float acc0[APM_RUN], acc1[APM_RUN];       // the run's values of rows lane and lane + 64 (newest last)
+#pragma unroll
+        for (int i = 0; i < APM_RUN; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+        int nrun = 0;
+
+        for (int64_t f = f_lo; f < f_hi; ++f) {
+            ap_float2 v[16];
+            {
+                ap_float2 w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], w[j]);
+            }
+            const bool clip_ends = t + 1 == Ti;
+            const bool more = f + 1 < f_hi;
+            AP_SCHED_FENCE();
+            apm_forward(v, X, TW1, lc.tw2row, lc, lm);
+            // The next frame of this wave's stretch: all 16 sample pairs again, issued only now that the
+            // transform's registers are free, in flight during split + contraction.  (Keeping the
+            // n_fft - hop shared samples in registers, as ap_mel2048_wave_kernel does, costs 32 VGPRs
+            // for the whole frame - the difference between 2 and 3 waves per SIMD; the re-read is
+            // served by L2.)
+            AP_SCHED_FENCE();
+            if (more) {
+                if (clip_ends) {                  // next clip starts
+                    clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
+                    load_frame(0);
+                } else {
+                    load_frame(t + 1);
+                }
+            }
+            AP_SCHED_FENCE();
+            {
+                ap_float2 xk[8], xm[8], zh;
+                apw_split<false>(X, lc, xk, xm, zh);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int k = lane + 64 * r;
+                    pp[k] = apw_pow2x<PMODE>(xk[r].x, xk[r].y, P.power);
+                    pp[APW_NC - k] = apw_pow2x<PMODE>(xm[r].x, xm[r].y, P.power);
+                }
+                if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(zh.x, zh.y, P.power);
+            }
+            AP_WAVE_SYNC();
+            // ---- plan-based contraction: NPASS branch-free passes (kernels_wave.h) -------------
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const ap_float4 *wq = WQ + 256 * ps + lane;
+                ap_float4 w[4], q[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = wq[64 * i];
+                q[0] = pqa[ps][0]; q[1] = pqa[ps][1]; q[2] = pqb[ps][0]; q[3] = pqb[ps][1];
+                float acc[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i >> 1] = fmaf(w[i].x, q[i].x, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w[i].y, q[i].y, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w[i].z, q[i].z, acc[i >> 1]);
+                    acc[i >> 1] = fmaf(w[i].w, q[i].w, acc[i >> 1]);
+                }
+                *sa[ps] = fmaf(fz[ps], acc[1], acc[0]);
+                *sb[ps] = acc[1];
+            }
+            AP_WAVE_SYNC();
+            // ---- row sums (<= 4 adjacent slots per row) into the run's registers ---------------
+            float sum2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float p0 = partial[rs0[i]], p1 = partial[rs0[i] + 1], p2 = partial[rs0[i] + 2],
+                            p3 = partial[rs0[i] + 3];
+                float sum = cnt[i] > 0 ? p0 : 0.0f;
+                sum += cnt[i] > 1 ? p1 : 0.0f;
+                sum += cnt[i] > 2 ? p2 : 0.0f;
+                sum += cnt[i] > 3 ? p3 : 0.0f;
+                sum2[i] = sum;
+                vmax = fmaxf(vmax, cnt[i] > 0 ? sum : vmax);
+            }
+#pragma unroll
+            for (int i = 0; i < APM_RUN - 1; ++i) { acc0[i] = acc0[i + 1]; acc1[i] = acc1[i + 1]; }
+            acc0[APM_RUN - 1] = sum2[0];
+            acc1[APM_RUN - 1] = sum2[1];
+            ++nrun;
+            AP_WAVE_SYNC();
+            // ---- store the run when it is full, the clip ends or the stretch ends ---------------
+            if (nrun == APM_RUN || clip_ends || !more) {
+                // frame t - nrun + 1 + g sits in register APM_RUN - nrun + g
+                float *ob = P.out + b * (int64_t)M * P.T + (t - nrun + 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = lane + 64 * i;
+                    if (row < M) {
+                        float *dst = ob + (int64_t)row * P.T;
+                        const float *src = i == 0 ? acc0 : acc1;
+                        if (nrun == APM_RUN) {      // 32 contiguous bytes: two 16-byte stores (4-byte aligned)
+                            ap_rsp_f4u lo, hi;
+                            lo.x = src[0]; lo.y = src[1]; lo.z = src[2]; lo.w = src[3];
+                            hi.x = src[4]; hi.y = src[5]; hi.z = src[6]; hi.w = src[7];
+                            *reinterpret_cast<ap_rsp_f4u *>(dst) = lo;
+                            *reinterpret_cast<ap_rsp_f4u *>(dst + 4) = hi;
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < APM_RUN; ++g)
+                                if (g >= APM_RUN - nrun) dst[g - (APM_RUN - nrun)] = src[g];
+                        }
+                    }
+                }
+                nrun = 0;
+            }
+            if (clip_ends) { t = 0; ++b; } else { ++t; }
+        }
+    }
+    if (P.max_key) {                  // one atomic per wave: lanes -> LDS -> lane 0
+        AP_WAVE_SYNC();
+        partial[lane] = vmax;
+        AP_WAVE_SYNC();
+        if (lane == 0) {
+            float m = partial[0];
+            for (int i = 1; i < 64; ++i) m = fmaxf(m, partial[i]);
+            ap_atomic_max_u32(P.max_key, ap_fkey(m));
+        }
+    }
+}

@@ -76,6 +76,7 @@ AP_DEV float apw_pow2x(float re, float im, float power) {
 struct ApClip { const float *base; int64_t n; };
 AP_DEV ApClip ap_clip_make(const float *base, int64_t n) { ApClip c; c.base = base; c.n = n; return c; }
 AP_DEV float ap_clip_load(const ApClip &c, int64_t idx) { return (idx >= 0 && idx < c.n) ? c.base[idx] : 0.0f; }
+AP_DEV ap_float2 ap_clip_load2(const ApClip &c, int64_t idx) { return ap_mk(ap_clip_load(c, idx), ap_clip_load(c, idx + 1)); }
 #else
 #define AP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler x is wave-uniform
 // one clip as a raw buffer resource: the hardware range check returns 0 for every sample
@@ -87,6 +88,12 @@ AP_DEV ApClip ap_clip_make(const float *base, int64_t n) {
 AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
     // a negative index wraps to a huge unsigned byte offset: out of range -> 0
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c, (int)(idx * 4), 0, 0));
+}
+// samples idx, idx + 1 (idx even or odd: the clip base is 4-byte aligned) as one 8-byte load; the
+// range check is per dword, so a pair that straddles either end of the clip still pads with 0
+AP_DEV ap_float2 ap_clip_load2(ApClip c, int idx) {
+    typedef int ap_i2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(ap_float2, __builtin_bit_cast(ap_i2, __builtin_amdgcn_raw_buffer_load_b64(c, idx * 4, 0, 0)));
 }
 #endif
 

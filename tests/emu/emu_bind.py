@@ -95,7 +95,7 @@ def mel_plan(fb):
 
 
 def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, banded=True,
-            force_generic=False, return_max=False):
+            force_generic=False, return_max=False, tile_kernel=False):
     y = np.ascontiguousarray(y, np.float32)
     B, L = y.shape
     T = n_frames(L, n_fft, hop, center)
@@ -110,6 +110,8 @@ def melspec(y, n_fft, hop, window, fb, center=True, pad_mode=0, power=2.0, bande
             desc[0] = 0                      # dense contraction (no band spans, no parts)
         if force_generic:
             desc[0] |= 256                   # AP_PLAN_FORCE_GENERIC: keep the generic LDS engine
+        if tile_kernel:
+            desc[0] |= 512                   # emulator-only: n_fft=2048 tile kernel instead of the run kernel
         plan_p, desc_p = plan.ctypes.data_as(_i32p), desc.ctypes.data_as(_i32p)
     else:
         plan_p = desc_p = None

@@ -13,6 +13,7 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/kernels_bigfft.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_ct.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave512.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_mel2048.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -107,7 +108,18 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
     if (rc != AP_OK) return rc;
     if (ap_mel_wave_eligible(n_fft, plan, desc)) {
         ApMelWaveParams W;
-        int grid = 0;
+        int grid = 0, n_pass = 0;
+        // the 12-wave run kernel where it applies (desc[0] & 512: test-only flag that keeps the tile kernel)
+        if (!(desc[0] & 512) && (power == 2.0f || power == 1.0f) &&
+            ap_prepare_mel_run(W, P, B, plan, desc, APM_WAVES, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
+            if (grid > 1) grid = 1;   // exercise the persistent frame loop
+            if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
+#define EMU_RUN(PM, NP) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP>(W); })
+            if (power == 2.0f) { if (n_pass == 1) EMU_RUN(2, 1); else if (n_pass == 2) EMU_RUN(2, 2); else if (n_pass == 3) EMU_RUN(2, 3); else EMU_RUN(2, 4); }
+            else { if (n_pass == 1) EMU_RUN(1, 1); else if (n_pass == 2) EMU_RUN(1, 2); else if (n_pass == 3) EMU_RUN(1, 3); else EMU_RUN(1, 4); }
+#undef EMU_RUN
+            return AP_OK;
+        }
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
             if (grid > 1) grid = 1;   // exercise the persistent tile loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }

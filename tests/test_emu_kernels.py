@@ -95,6 +95,12 @@ def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
                           pad_mode=pad_mode, **kw)
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
     assert amax == A.max()            # the key the kernel raises for mfcc's top_db clip
+    # constant padding with power 2 / 1 runs on the 12-wave run kernel (kernels_mel2048.h); the 8-wave
+    # tile kernel (kernels_wave.h) keeps serving the other shapes and must agree
+    A2, amax2 = eb.melspec(y, 2048, 512, win, fb, power=power, pad_mode=PM[pad_mode], return_max=True,
+                           tile_kernel=True)
+    np.testing.assert_allclose(A2, R, rtol=1e-4, atol=1e-4)
+    assert amax2 == A2.max()
 
 
 @pytest.mark.parametrize("sr,M,kw", [
@@ -110,12 +116,13 @@ def test_emu_wave_kernel_unusual_filterbanks(sr, M, kw):
     y = rng.standard_normal((2, 6000)).astype(np.float32)
     win = ao.padded_window("hann", 2048, 2048)
     fb = ao.mel_filterbank(sr, 2048, M, **kw)
-    A, amax = eb.melspec(y, 2048, 512, win, fb, return_max=True)
-    A0 = eb.melspec(y, 2048, 512, win, fb)
     R = ao.melspectrogram(y, sr=sr, n_fft=2048, hop_length=512, n_mels=M, **kw)
-    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
-    np.testing.assert_array_equal(A, A0)
-    assert amax == A.max()
+    for tile_kernel in (False, True):
+        A, amax = eb.melspec(y, 2048, 512, win, fb, return_max=True, tile_kernel=tile_kernel)
+        A0 = eb.melspec(y, 2048, 512, win, fb, tile_kernel=tile_kernel)
+        np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+        np.testing.assert_array_equal(A, A0)
+        assert amax == A.max()
     # every wave stages its 64 lane maxima in its own partial-sum region
     assert eb.mel_wave_partial_stride(fb) >= 64
 
@@ -128,9 +135,10 @@ def test_emu_wave_kernel_hops(hop):
     y = rng.standard_normal((2, 7000)).astype(np.float32)
     win = ao.padded_window("hann", 2048, 2048)
     fb = ao.mel_filterbank(22050, 2048, 64)
-    A = eb.melspec(y, 2048, hop, win, fb)
     R = ao.melspectrogram(y, sr=22050, n_fft=2048, hop_length=hop, n_mels=64)
-    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    for tile_kernel in (False, True):
+        A = eb.melspec(y, 2048, hop, win, fb, tile_kernel=tile_kernel)
+        np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("hop,M,L,B,power", [(256, 128, 9000, 2, 2.0), (128, 80, 5000, 1, 1.0),

@@ -37,11 +37,11 @@ __global__ void __launch_bounds__(1024) k_valu(float *out, unsigned long long *s
     else if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));                \
     else if (KIND == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                            \
     else if (KIND == 3) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));                            \
-    else if (KIND == 4) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a[i].x) : "v"(a[(i + 8) & 15].y)); \
+    else if (KIND == 4) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y)); \
     else if (KIND == 5) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(c.x)); \
     else if (KIND == 6) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));                           \
-    else if (KIND == 7) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x) : ); \
-    else if (KIND == 8) asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x)); \
+    else if (KIND == 7) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x) : ); \
+    else if (KIND == 8) asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x)); \
     else if (KIND == 9) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(a[i]) : "v"(b), "v"(c)); \
     else if (KIND == 10) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(c.y));                           \
     else if (KIND == 11) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(b.x), "v"(c.x)); asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].y) : "v"(b.y), "v"(c.y)); }
@@ -101,6 +101,7 @@ static void run(const char *name, K kernel, int waves_per_simd, int instr_per_it
                 float *out, unsigned long long *stamps_d) {
     const int threads = 256 * waves_per_simd, blocks = 256;
     const int n_waves = blocks * threads / 64;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -119,11 +120,14 @@ static void run(const char *name, K kernel, int waves_per_simd, int instr_per_it
     std::sort(ghz.begin(), ghz.end());
     const double n_instr = (double)instr_per_iter * iters;
     const double med = cyc[n_waves / 2];
-    std::printf("%-28s waves/SIMD %d  cycles/instr/wave %7.2f  -> SIMD cycles/instr %6.2f   clock %.2f GHz   kernel %.3f ms\n",
-                name, waves_per_simd, med / n_instr, med / n_instr / waves_per_simd, ghz[n_waves / 2], ms);
+    const double agg = ms * 1e-3 * ghz[n_waves / 2] * 1e9 / (n_instr * waves_per_simd);
+    std::printf("%-26s waves/SIMD %d  per-wave cyc/instr %6.2f (/waves %5.2f)  kernel-time cyc/instr/SIMD %5.2f  clock %.2f GHz  %.3f ms\n",
+                name, waves_per_simd, med / n_instr, med / n_instr / waves_per_simd, agg, ghz[n_waves / 2], ms);
     CHECK(hipEventDestroy(e0));
     CHECK(hipEventDestroy(e1));
 }
+
+static const size_t LDSB = 100 * 1024;   // > half of the CU's 160 KiB: one workgroup per CU
 
 int main() {
     float *out;
@@ -134,28 +138,28 @@ int main() {
     const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_mov_b32_dpp", "v_fmac_f32_dpp",
                            "v_add_f32", "v_cndmask_b32", "v_add_f32_dpp", "v_pk_fma_f32 op_sel/neg", "v_mul_f32", "2x v_fma_f32 (x,y)"};
     for (int wps = 1; wps <= 4; ++wps) {
-        run(names[0], k_valu<0>, wps, 64, iters, 0, out, stamps);
-        run(names[1], k_valu<1>, wps, 64, iters, 0, out, stamps);
-        run(names[2], k_valu<2>, wps, 64, iters, 0, out, stamps);
-        run(names[3], k_valu<3>, wps, 64, iters, 0, out, stamps);
-        run(names[4], k_valu<4>, wps, 64, iters, 0, out, stamps);
-        run(names[5], k_valu<5>, wps, 64, iters, 0, out, stamps);
-        run(names[6], k_valu<6>, wps, 64, iters, 0, out, stamps);
-        run(names[7], k_valu<7>, wps, 64, iters, 0, out, stamps);
-        run(names[8], k_valu<8>, wps, 64, iters, 0, out, stamps);
-        run(names[9], k_valu<9>, wps, 64, iters, 0, out, stamps);
-        run(names[10], k_valu<10>, wps, 64, iters, 0, out, stamps);
-        run(names[11], k_valu<11>, wps, 128, iters, 0, out, stamps);
+        run(names[0], k_valu<0>, wps, 64, iters, LDSB, out, stamps);
+        run(names[1], k_valu<1>, wps, 64, iters, LDSB, out, stamps);
+        run(names[2], k_valu<2>, wps, 64, iters, LDSB, out, stamps);
+        run(names[3], k_valu<3>, wps, 64, iters, LDSB, out, stamps);
+        run(names[4], k_valu<4>, wps, 64, iters, LDSB, out, stamps);
+        run(names[5], k_valu<5>, wps, 64, iters, LDSB, out, stamps);
+        run(names[6], k_valu<6>, wps, 64, iters, LDSB, out, stamps);
+        run(names[7], k_valu<7>, wps, 64, iters, LDSB, out, stamps);
+        run(names[8], k_valu<8>, wps, 64, iters, LDSB, out, stamps);
+        run(names[9], k_valu<9>, wps, 64, iters, LDSB, out, stamps);
+        run(names[10], k_valu<10>, wps, 64, iters, LDSB, out, stamps);
+        run(names[11], k_valu<11>, wps, 128, iters, LDSB, out, stamps);
         std::printf("\n");
     }
     const char *lnames[] = {"ds_read_b64", "ds_read_b128", "ds_write_b64", "ds_write_b32", "ds_read_b32", "ds_bpermute_b32"};
     for (int wps = 1; wps <= 3; ++wps) {
-        run(lnames[0], k_lds<0>, wps, 16, iters, 65536, out, stamps);
-        run(lnames[1], k_lds<1>, wps, 16, iters, 65536, out, stamps);
-        run(lnames[2], k_lds<2>, wps, 16, iters, 65536, out, stamps);
-        run(lnames[3], k_lds<3>, wps, 16, iters, 65536, out, stamps);
-        run(lnames[4], k_lds<4>, wps, 16, iters, 65536, out, stamps);
-        run(lnames[5], k_lds<5>, wps, 16, iters, 65536, out, stamps);
+        run(lnames[0], k_lds<0>, wps, 16, iters, LDSB, out, stamps);
+        run(lnames[1], k_lds<1>, wps, 16, iters, LDSB, out, stamps);
+        run(lnames[2], k_lds<2>, wps, 16, iters, LDSB, out, stamps);
+        run(lnames[3], k_lds<3>, wps, 16, iters, LDSB, out, stamps);
+        run(lnames[4], k_lds<4>, wps, 16, iters, LDSB, out, stamps);
+        run(lnames[5], k_lds<5>, wps, 16, iters, LDSB, out, stamps);
         std::printf("\n");
     }
     return 0;
