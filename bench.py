@@ -9,7 +9,11 @@ rank owns its own batch, no data-path collective — SURVEY.md §8e):
     headline: B=256 clips x 10 s @ 22.05 kHz per GPU, n_fft=2048 hop=512 n_mels=128
               hann, center, constant pad, power 2, Slaney  -> T=431 frames/clip
 
-Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.  Before the W warm-up steps
+the same step runs untimed for --ramp-seconds (default 1 s): a fresh box idles at ~600 MHz and the
+power management needs a few hundred ms of load to settle on the sustained clock (2.2-2.35 GHz at
+~1 350 W for this kernel, tools/diag_clock.py); without it K = 20 steps of 0.2 ms time the ramp
+(0.27-0.28 ms/step) instead of the kernel.  The timed region is still exactly K steps.
 
 N > 1: one process per GPU.  Either the caller starts the ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, RANK / LOCAL_RANK /
@@ -51,6 +55,11 @@ def parse_args(argv=None):
     ap_.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap_.add_argument("--batch", type=int, default=None, help="clips per GPU (default: workload's)")
     ap_.add_argument("--no-cpu-baseline", action="store_true")
+    ap_.add_argument("--ramp-seconds", type=float, default=1.0,
+                     help="untimed pre-conditioning before the W warm-up steps: the same step run back to back "
+                          "for this long so the GPU leaves its low-power state (a fresh box starts at ~600 MHz "
+                          "and needs some hundreds of ms of load to reach its sustained clock; 25 launches of "
+                          "0.2 ms do not get it there and measure the ramp, not the kernel)")
     ap_.add_argument("--stub-step", action="store_true",
                      help="(tests) CPU ranks over gloo with a no-op step: exercises the launcher, the "
                           "barrier / max-over-ranks timing and the JSON contract without a GPU; the "
@@ -251,6 +260,12 @@ def main(argv=None):
         sync = torch.cuda.synchronize
         out = step(0)
         assert out.shape == (B, n_mels, T)
+    if not stub and args.ramp_seconds > 0:
+        t_r = time.perf_counter()
+        while time.perf_counter() - t_r < args.ramp_seconds:       # untimed: clock / power ramp-up
+            for i in range(25):
+                step(i)
+            sync()
     for i in range(args.warmup):
         step(i)
 

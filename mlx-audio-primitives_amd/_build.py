@@ -8,7 +8,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libaudioprims_hip.so")
+# AP_LIB_PATH: load another build of the same sources instead (diagnostic builds, tools/diag_clock.py)
+LIB_PATH = os.environ.get("AP_LIB_PATH") or os.path.join(PKG_DIR, "libaudioprims_hip.so")
 SOURCES = ["audioprims.hip", "host_builders.cpp"]
 
 
@@ -23,6 +24,8 @@ def _stale() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into one shared library."""
+    if os.environ.get("AP_LIB_PATH"):
+        return LIB_PATH
     if not force and not _stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -49,14 +49,14 @@ static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) 
 }
 
 // n_fft = 2048 run kernel (kernels_mel2048.h)
-template <int PMODE, int NW>
-static int ap_launch_mel_run(const ApMelWaveParams &W, int n_pass, int grid, void *stream) {
-#define AP_RUN_LAUNCH(NP)                                                                        \
-    do {                                                                                         \
-        int rc = ap_allow_lds(ap_mel2048_run_kernel<PMODE, NP, NW>, W.lds_bytes);                \
-        if (rc != AP_OK) return rc;                                                              \
-        hipLaunchKernelGGL((ap_mel2048_run_kernel<PMODE, NP, NW>), dim3(grid), dim3(64 * NW),    \
-                           W.lds_bytes, (hipStream_t)stream, W);                                 \
+template <int PMODE, int HOPJ>
+static int ap_launch_mel_run_h(const ApMelWaveParams &W, int n_pass, int grid, void *stream) {
+#define AP_RUN_LAUNCH(NP)                                                                          \
+    do {                                                                                           \
+        int rc = ap_allow_lds(ap_mel2048_run_kernel<PMODE, NP, HOPJ>, W.lds_bytes);                \
+        if (rc != AP_OK) return rc;                                                                \
+        hipLaunchKernelGGL((ap_mel2048_run_kernel<PMODE, NP, HOPJ>), dim3(grid), dim3(64 * APM_WAVES), \
+                           W.lds_bytes, (hipStream_t)stream, W);                                   \
     } while (0)
     if (n_pass == 1) AP_RUN_LAUNCH(1);
     else if (n_pass == 2) AP_RUN_LAUNCH(2);
@@ -64,6 +64,12 @@ static int ap_launch_mel_run(const ApMelWaveParams &W, int n_pass, int grid, voi
     else AP_RUN_LAUNCH(4);
 #undef AP_RUN_LAUNCH
     return ap_check_launch("ap_melspec_f32(run)");
+}
+template <int PMODE>
+static int ap_launch_mel_run(const ApMelWaveParams &W, int n_pass, int grid, void *stream) {
+    // hop = 512: the 1536 samples two consecutive frames share stay in registers
+    return W.hopj == 4 ? ap_launch_mel_run_h<PMODE, 4>(W, n_pass, grid, stream)
+                       : ap_launch_mel_run_h<PMODE, 0>(W, n_pass, grid, stream);
 }
 
 static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
@@ -104,6 +110,14 @@ static int ap_launch_mel_wave_p(const ApMelWaveParams &W, int grid, float power,
 extern "C" {
 
 int ap_version(void) { return 100; }
+
+#ifdef AP_DIAG_STAMPS
+// diagnostic build only: copy the per-wave (shader cycles, 100 MHz ticks) stamps to the host
+int ap_diag_read_stamps(unsigned long long *host, int n_words) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(ap_diag_stamps), sizeof(unsigned long long) * (size_t)n_words);
+    return e == hipSuccess ? AP_OK : AP_ERR_HIP;
+}
+#endif
 
 const char *ap_last_error(void) { return g_err; }
 
@@ -208,22 +222,18 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
     if (ap_mel_wave_eligible(n_fft, plan, desc)) {
         ApMelWaveParams W;
         int grid = 0, n_pass = 0;
-        // power 2 / 1 with constant padding and <= 128 filters: the 12-wave run kernel
-        // (AP_MEL2048_WAVE=1 keeps the 8-wave tile kernel for A/B timing)
+        // power 2 / 1 with constant padding and <= 128 filters: the run kernel (kernels_mel2048.h);
+        // AP_MEL2048_WAVE=1 keeps the tile kernel for A/B timing (tools/mel_ab.py)
         static const bool force_wave = std::getenv("AP_MEL2048_WAVE") != nullptr;
-        static const int run_waves = std::getenv("AP_MEL2048_RUN8") ? 8 : APM_WAVES;     // (experiment switch)
         if (!force_wave && (power == 2.0f || power == 1.0f) &&
-            ap_prepare_mel_run(W, P, B, plan, desc, run_waves, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
+            ap_prepare_mel_run(W, P, B, plan, desc, APM_WAVES, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
             if (max_key_dev) {
                 hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
                 if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
                 W.max_key = max_key_dev;
             }
-            if (run_waves == 8)
-                return power == 2.0f ? ap_launch_mel_run<2, 8>(W, n_pass, grid, stream)
-                                     : ap_launch_mel_run<1, 8>(W, n_pass, grid, stream);
-            return power == 2.0f ? ap_launch_mel_run<2, APM_WAVES>(W, n_pass, grid, stream)
-                                 : ap_launch_mel_run<1, APM_WAVES>(W, n_pass, grid, stream);
+            return power == 2.0f ? ap_launch_mel_run<2>(W, n_pass, grid, stream)
+                                 : ap_launch_mel_run<1>(W, n_pass, grid, stream);
         }
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
             if (max_key_dev) {            // the kernel raises the key itself: one atomic per wave

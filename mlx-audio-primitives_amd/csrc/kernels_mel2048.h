@@ -1,31 +1,36 @@
-// Fused mel-spectrogram for n_fft = 2048, the run kernel: 12 independent waves per CU, each wave
+// Fused mel-spectrogram for n_fft = 2048, the run kernel: 8 independent waves per CU, each wave
 // one frame at a time in registers + its own LDS exchange buffer, output runs in registers.
 //
 // Same transform and contraction as ap_mel2048_wave_kernel (kernels_wave.h: 16 x 16 x 4 complex
 // transform of the packed frame, paired real split, |X|^p plane, plan-based banded contraction),
-// re-cut around what rocprofv3 showed that kernel waiting for (profiles/README.md): with 8 waves
-// per CU a wave issues one instruction every 4-5 cycles whatever its kind, the frame loop carried
-// ~1000 of them (a 64-bit division per frame for (clip, frame), a branch ladder over the hop
-// variants, exec-mask juggling for rows >= n_mels, 64 v_mov_b32_dpp + 64 packed ops for a radix-4
-// that needs 64 + 48), and the LDS pipe and the VALUs were each ~60-65 % busy.  So:
+// re-cut around what the round-2 measurements showed (profiles/README.md, tools/diag_clock.py,
+// tools/power_probe.py):
 //
-//   * everything frame-invariant is a template parameter or a register: number of contraction
-//     passes (NPASS), (clip, frame) advanced incrementally, part descriptors as
-//     ready-made LDS addresses, rows >= n_mels computed like the others and simply not stored;
+//   * the chip runs this kernel at its POWER limit (1 340-1 355 W of board power, shader clock
+//     2.2-2.35 GHz and falling whenever the pipes are kept busier): what shortens a launch is
+//     less energy per frame - fewer instructions, fewer LDS and L2 bytes - not more waves (a
+//     12-wave, 168-VGPR build spilled; alternating priorities between the co-resident waves
+//     evened out their speeds and lowered the clock by the same factor);
+//   * so everything frame-invariant is a template parameter or a register: the number of
+//     contraction passes (NPASS), the hop class (HOPJ), (clip, frame) advanced incrementally
+//     instead of a 64-bit division per frame, part descriptors as ready-made LDS addresses, rows
+//     >= n_mels computed like the others and simply not stored, the window pairs and the split
+//     twiddles of the lane in registers for the whole kernel (46 VGPRs: 16 LDS reads and 14
+//     packed multiplies fewer per frame);
 //   * the quad radix-4 runs on v_fmac_f32_dpp: the DPP operand feeds the FMA directly
-//     (h += c * quad_perm(h)), the two per-lane signs are folded into the W_64 twiddles that
-//     precede it and the -i of lane 3 is two v_cndmask;
+//     (h += c * quad_perm(h)) and the two per-lane signs are folded into the W_64 twiddles that
+//     precede it - 64 DPP FMAs + 48 plain ops instead of 64 DPP moves + 64 packed ops;
 //   * the 8-frame output run of a lane's two mel rows lives in registers (32 contiguous bytes per
-//     row and lane, as in ap_mel1024_wave_kernel): no output tile in LDS, and the partial sums
-//     alias the idle upper half of the wave's exchange buffer -> 10 KB of LDS per wave,
-//     12 waves + all tables = 152 KB per CU, <= 168 VGPRs: three waves per SIMD.
+//     row and lane, as in ap_mel1024_wave_kernel): no output tile in LDS; the partial sums
+//     alias the idle upper half of the wave's exchange buffer.
 //
-// Serves constant padding / center=False, n_mels <= 128, plans of <= 256 entries whose rows have
-// <= 4 parts; everything else stays on ap_mel2048_wave_kernel.  Reference: mel.py:245-352.
+// Serves constant padding / center=False, power 2 or 1, n_mels <= 128, plans of <= 256 entries
+// whose rows have <= 4 parts; everything else stays on ap_mel2048_wave_kernel.
+// Reference: mel.py:245-352 (stft.py:130 + mel.py:344-350).
 #pragma once
 #include "kernels_wave.h"
 
-#define APM_WAVES 12          // waves per workgroup (3 per SIMD)
+#define APM_WAVES 8           // waves per workgroup (2 per SIMD, 256 VGPRs each)
 #define APM_RUN 8             // frames per output run held in registers
 #define APM_PARTIAL_OFF 1152  // float offset of the partial sums inside the wave's X buffer (plane: 1025 floats)
 
@@ -113,11 +118,25 @@ AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
     }
 }
 
-// forward transform of apw_forward with the fmac-DPP quad stage; tw2s holds sg * W_64^(a c)
+// Which frame-invariant per-lane tables stay in REGISTERS for the whole kernel instead of being
+// re-read from LDS every frame (bit mask; 8 waves per CU leave 256 VGPRs per lane).  The product
+// uses APM_REGS: with the two twiddle tables as well hipcc's scheduler spills inside the frame loop.
+#define APM_REG_WIN 1         // window pairs                 32 VGPRs, saves 16 ds_read_b64 per frame
+#define APM_REG_TW1 2         // W_1024^(lane k1)             30 VGPRs, saves 15
+#define APM_REG_TW2 4         // (s1 s2) W_64^(a c)           30 VGPRs, saves 15
+#define APM_REG_SPLIT 8       // W_2048^(lane + 64 r) / 2     14 VGPRs, saves 14 packed multiplies
+#define APM_REGS (APM_REG_WIN | APM_REG_SPLIT)
+
+// forward transform of apw_forward with the fmac-DPP quad stage; tw2row holds sg * W_64^(a c)
+template <int REGS>
 AP_DEV void apm_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ap_float2 *tw2row,
-                        const ApwLane &c, const ApmLane &m) {
+                        const ap_float2 (&t1r)[16], const ap_float2 (&t2r)[16], const ApwLane &c, const ApmLane &m) {
     const int lane = c.lane;
-    {
+    if (REGS & APM_REG_TW1) {
+        ApButterfly<16>::run(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1r[k]);
+    } else {
         ap_float2 t1[16];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];
@@ -134,20 +153,82 @@ AP_DEV void apm_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
     ap_float2 t2[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = X[APW_T1(lane) + i];
+    if (!(REGS & APM_REG_TW2)) {
 #pragma unroll
-    for (int cc = 1; cc < 16; ++cc) t2[cc] = tw2row[cc];
+        for (int cc = 1; cc < 16; ++cc) t2[cc] = tw2row[cc];
+    }
     AP_WAVE_SYNC();
     ApButterfly<16>::run(v);
     v[0] = ap_scale(v[0], m.sg);
 #pragma unroll
-    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);
+    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], (REGS & APM_REG_TW2) ? t2r[cc] : t2[cc]);
     apm_quad_radix4(v, m);
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) X[apw_zidx(c.k1p + 16 * cc + 256 * c.qd)] = v[cc];
     AP_WAVE_SYNC();
 }
 
-template <int PMODE, int NPASS, int NW = APM_WAVES>
+// apw_split (kernels_wave.h) for |X| only, with the eight split twiddles W_2048^(lane + 64 r) / 2
+// optionally held in registers
+template <int REGS>
+AP_DEV void apm_split(const ap_float2 *X, const ApwLane &c, const ap_float2 (&wsp)[8], ap_float2 (&xk)[8],
+                      ap_float2 (&xm)[8], ap_float2 &zh) {
+    ap_float2 zk[8], zm[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = c.lane + 64 * r;
+        zk[r] = X[apw_zidx(k)];
+        zm[r] = X[apw_zidx((APW_NC - k) & (APW_NC - 1))];
+    }
+    zh = X[apw_zidx(APW_NC / 2)];
+    AP_WAVE_SYNC();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const ap_float2 a = ap_add_conj(zk[r], zm[r]);
+        const ap_float2 d = ap_sub_conj(zk[r], zm[r]);
+        const ap_float2 w = (REGS & APM_REG_SPLIT) ? wsp[r]
+                                                   : (r == 0 ? c.tws0h : ap_mul_bw_c(c.tws0h, APW_C32(r), APW_S32(r)));
+        const ap_float2 u = ap_mul_fw(d, w);
+        xk[r] = ap_fma_add_mi(a, c.half, u);
+        xm[r] = ap_fma_sub_mi(a, c.half, u);
+    }
+}
+
+#ifdef AP_DIAG_STAMPS
+// Diagnostic build only (tools/diag_clock.py; buffer in kernels_wave.h)
+#define AP_DIAG_BEGIN() unsigned long long ap_dt0, ap_dr0; \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ap_dt0), "=s"(ap_dr0)::"memory")
+#define AP_DIAG_END(widx) do { unsigned long long ap_dt1, ap_dr1; \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ap_dt1), "=s"(ap_dr1)::"memory"); \
+    if ((threadIdx.x & 63) == 0 && (widx) < 256 * 16) { ap_diag_stamps[4 * (widx)] = ap_dt1 - ap_dt0; ap_diag_stamps[4 * (widx) + 1] = ap_dr1 - ap_dr0; ap_diag_stamps[4 * (widx) + 2] = ap_dr0; ap_diag_stamps[4 * (widx) + 3] = ap_dr1; } } while (0)
+#else
+#define AP_DIAG_BEGIN() do {} while (0)
+#define AP_DIAG_END(widx) do {} while (0)
+#endif
+
+// The two (three) waves of a SIMD do not share it evenly: issue is arbitrated by priority, then AGE,
+// so the first-dispatched wave of every SIMD ran its 54 frames in 144 us and the second in 186 us
+// (tools/diag_clock.py), and the kernel lasts as long as the slow one.  The later-dispatched waves
+// therefore raise their priority on every other frame: over two frames each side wins once, all
+// waves finish together and the SIMDs stay shared until the end.  (At the power limit this buys
+// nothing by itself - the clock drops as the SIMDs stay busier - but it keeps the tail short
+// whenever the kernel is not power-bound: short batches, cooler boards.)
+#ifdef AP_HOST_EMU
+#define AP_FAIR_SHARE(wave, nw, f) do {} while (0)
+#else
+#define AP_FAIR_SHARE(wave, nw, f)                                   \
+    do {                                                             \
+        if ((wave) >= (nw) / 2 + ((nw) > 8 ? 2 : 0)) {               \
+            if ((f) & 1) __builtin_amdgcn_s_setprio(1);              \
+            else __builtin_amdgcn_s_setprio(0);                      \
+        } else if ((nw) > 8 && (wave) >= 4) {                        \
+            if ((f) & 1) __builtin_amdgcn_s_setprio(0);              \
+            else __builtin_amdgcn_s_setprio(1);                      \
+        }                                                            \
+    } while (0)
+#endif
+
+template <int PMODE, int NPASS, int HOPJ, int NW = APM_WAVES, int REGS = APM_REGS>
 __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWaveParams P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -177,6 +258,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
     }
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     const ApmLane lm = apm_lane_init(lane);
+    // per-lane tables kept in registers (REGS): straight from the global tables
+    ap_float2 winr[16], t1r[16], t2r[16], wsp[8];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        winr[j] = (REGS & APM_REG_WIN) ? reinterpret_cast<const ap_float2 *>(P.window)[lane + 64 * j] : ap_mk(0.0f, 0.0f);
+        t1r[j] = (REGS & APM_REG_TW1) ? P.tw[(2 * lane * j) & 2047] : ap_mk(0.0f, 0.0f);        // W_1024^(lane j)
+        t2r[j] = (REGS & APM_REG_TW2) ? ap_scale(P.tw[32 * (lane & 3) * j], lm.sg) : ap_mk(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        wsp[r] = (REGS & APM_REG_SPLIT) ? ap_scale(P.tw[lane + 64 * r], 0.5f) : ap_mk(0.0f, 0.0f);
     // frame-invariant contraction state: LDS addresses of this lane's entries
     const ap_float4 *pqa[NPASS], *pqb[NPASS];
     float *sa[NPASS], *sb[NPASS];
@@ -208,6 +300,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
     const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
     const int Ti = (int)P.T;
     float vmax = -INFINITY;
+    AP_DIAG_BEGIN();
     if (f_lo < f_hi) {
         int64_t b = f_lo / P.T;                   // the only division: (clip, frame) advance incrementally
         int t = (int)(f_lo - b * P.T);
@@ -228,8 +321,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
         int nrun = 0;
 
         for (int64_t f = f_lo; f < f_hi; ++f) {
+            AP_FAIR_SHARE(wave, NW, f);
             ap_float2 v[16];
-            {
+            if (REGS & APM_REG_WIN) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], winr[j]);
+            } else {
                 ap_float2 w[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
@@ -239,25 +336,29 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
             const bool clip_ends = t + 1 == Ti;
             const bool more = f + 1 < f_hi;
             AP_SCHED_FENCE();
-            apm_forward(v, X, TW1, lc.tw2row, lc, lm);
-            // The next frame of this wave's stretch: all 16 sample pairs again, issued only now that the
-            // transform's registers are free, in flight during split + contraction.  (Keeping the
-            // n_fft - hop shared samples in registers, as ap_mel2048_wave_kernel does, costs 32 VGPRs
-            // for the whole frame - the difference between 2 and 3 waves per SIMD; the re-read is
-            // served by L2.)
+            apm_forward<REGS>(v, X, TW1, lc.tw2row, t1r, t2r, lc, lm);
+            // The next frame of this wave's stretch, in flight during split + contraction
             AP_SCHED_FENCE();
             if (more) {
                 if (clip_ends) {                  // next clip starts
                     clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
                     load_frame(0);
-                } else {
+                } else if (HOPJ == 0) {
                     load_frame(t + 1);
+                } else {
+                    // hop = 128 HOPJ: pair j of frame t + 1 is pair j + HOPJ of frame t - only the HOPJ
+                    // new pairs are loaded (the shared samples stay in registers across the frame)
+                    const int base = (t + 1) * P.hop - P.pad;
+#pragma unroll
+                    for (int j = 0; j < 16 - HOPJ; ++j) raw[j] = raw[j + HOPJ];
+#pragma unroll
+                    for (int j = 16 - HOPJ; j < 16; ++j) raw[j] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
                 }
             }
             AP_SCHED_FENCE();
             {
                 ap_float2 xk[8], xm[8], zh;
-                apw_split<false>(X, lc, xk, xm, zh);
+                apm_split<REGS>(X, lc, wsp, xk, xm, zh);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int k = lane + 64 * r;
@@ -334,6 +435,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
             if (clip_ends) { t = 0; ++b; } else { ++t; }
         }
     }
+    AP_DIAG_END((int)worker);
     if (P.max_key) {                  // one atomic per wave: lanes -> LDS -> lane 0
         AP_WAVE_SYNC();
         partial[lane] = vmax;

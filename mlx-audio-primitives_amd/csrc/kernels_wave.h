@@ -28,6 +28,13 @@
 #include "fft_lds.h"
 #include "kernels_generic.h"
 
+#if defined(AP_DIAG_STAMPS) && !defined(AP_HOST_EMU)
+// Diagnostic build only (tools/diag_clock.py): every wave of the n_fft=2048 mel kernels records how
+// long its frame loop took in shader cycles (s_memtime) and in 100 MHz ticks (s_memrealtime) ->
+// the clock the chip held under this load.  Never compiled into the product library.
+__device__ unsigned long long ap_diag_stamps[4 * 256 * 16];
+#endif
+
 // cos/sin(2 pi r / 32), r = 0..7, as compile-time constants (W_2048^(64 r) = W_32^r)
 #define APW_C32(r) ((float)__builtin_cos(6.283185307179586476925 * (r) / 32.0))
 #define APW_S32(r) ((float)__builtin_sin(6.283185307179586476925 * (r) / 32.0))
@@ -279,6 +286,10 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
     const int64_t n_frames = P.n_clips * P.T;
     const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
     float vmax = -INFINITY;           // running max of this lane's mel values (mfcc's top_db clip needs the global one)
+#ifdef AP_DIAG_STAMPS
+    unsigned long long ap_dt0, ap_dr0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ap_dt0), "=s"(ap_dr0)::"memory");
+#endif
     ap_float2 raw[16];
     auto load_frame = [&](int64_t f) {
         const int64_t b = f / P.T;
@@ -450,6 +461,13 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
         AP_WAVE_SYNC();
         f += Gt;
     }
+#ifdef AP_DIAG_STAMPS
+    {
+        unsigned long long ap_dt1, ap_dr1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ap_dt1), "=s"(ap_dr1)::"memory");
+        if (lane == 0 && worker < 256 * 16) { ap_diag_stamps[4 * worker] = ap_dt1 - ap_dt0; ap_diag_stamps[4 * worker + 1] = ap_dr1 - ap_dr0; ap_diag_stamps[4 * worker + 2] = ap_dr0; ap_diag_stamps[4 * worker + 3] = ap_dr1; }
+    }
+#endif
     if (P.max_key) {                  // one atomic per wave: lanes -> LDS -> lane 0
         partial[lane] = vmax;
         AP_WAVE_SYNC();

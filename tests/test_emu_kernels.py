@@ -95,7 +95,7 @@ def test_emu_wave_kernel(sr, M, L, B, power, pad_mode, kw):
                           pad_mode=pad_mode, **kw)
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
     assert amax == A.max()            # the key the kernel raises for mfcc's top_db clip
-    # constant padding with power 2 / 1 runs on the 12-wave run kernel (kernels_mel2048.h); the 8-wave
+    # constant padding with power 2 / 1 runs on the run kernel (kernels_mel2048.h); the
     # tile kernel (kernels_wave.h) keeps serving the other shapes and must agree
     A2, amax2 = eb.melspec(y, 2048, 512, win, fb, power=power, pad_mode=PM[pad_mode], return_max=True,
                            tile_kernel=True)

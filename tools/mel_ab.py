@@ -4,7 +4,7 @@ HIP-event times.   usage: python tools/mel_ab.py [rounds]      (variants: env sw
 import json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = {"wave8(v1)": {"AP_MEL2048_WAVE": "1"}, "run8": {"AP_MEL2048_RUN8": "1"}, "run12": {}}
+VARIANTS = {"wave(tile)": {"AP_MEL2048_WAVE": "1"}, "run": {}}
 CHILD = r'''
 import sys, json, numpy as np, torch
 sys.path.insert(0, %r)
@@ -19,13 +19,18 @@ kw = dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128)
 rng = np.random.default_rng(0)
 ysmall = rng.standard_normal((3, 30000)).astype(np.float32)
 err = float(np.max(np.abs(ap.melspectrogram(torch.from_numpy(ysmall).cuda(), **kw).cpu().numpy() - ao.melspectrogram(ysmall, **kw))))
-for i in range(5): ap.melspectrogram(ys[i %% 3], **kw)
-torch.cuda.synchronize()
+import time
+t0 = time.time()
+while time.time() - t0 < 1.0:                      # bring the clocks up (a cold GPU runs ~25 %% slower)
+    for i in range(50): ap.melspectrogram(ys[i %% 3], **kw)
+    torch.cuda.synchronize()
 ts = []
-for i in range(30):
+for rep in range(5):                                # back-to-back streams of 200 launches
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ap.melspectrogram(ys[i %% 3], **kw); e1.record(); torch.cuda.synchronize()
-    ts.append(e0.elapsed_time(e1))
+    e0.record()
+    for i in range(200): ap.melspectrogram(ys[i %% 3], **kw)
+    e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 200)
 ts.sort()
 print(json.dumps({"median_ms": ts[len(ts)//2], "min_ms": ts[0], "max_abs_err_vs_oracle": err}))
 ''' % ROOT
@@ -45,4 +50,4 @@ for name, rs in res.items():
     if rs:
         med = sorted(r["median_ms"] for r in rs)[len(rs) // 2]
         print(f"{name:12s} median {med:.4f} ms  min {min(r['min_ms'] for r in rs):.4f} ms  "
-              f"{frames / med / 1e6:.1f} M frames/s  err {max(r['max_abs_err_vs_oracle'] for r in rs):.2e}")
+              f"{frames / med / 1e3:.1f} M frames/s  err {max(r['max_abs_err_vs_oracle'] for r in rs):.2e}")

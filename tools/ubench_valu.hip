@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); std::exit(1); } } while (0)
@@ -22,11 +23,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int KIND>
 __global__ void __launch_bounds__(1024) k_valu(float *out, unsigned long long *stamps, int iters, float seed) {
     f2 a[16], b, c;
-    b = f2{seed, seed * 0.5f};
-    c = f2{seed * 0.25f, 1.0f};
+    unsigned h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + 12345u;
+    auto rnd = [&]() { h = h * 1664525u + 1013904223u; return __builtin_bit_cast(float, 0x3f000000u | (h >> 9)) * ((h & 256) ? 1.0f : -1.0f); };
+    b = f2{rnd(), rnd()};
+    c = f2{rnd() * seed, rnd()};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = f2{seed + i, seed - i};
+    for (int i = 0; i < 16; ++i) a[i] = f2{rnd(), rnd()};
     float sc = seed;
+    const unsigned long long smask = 0x8888888888888888ull;
     unsigned long long t0, r0, t1, r1;
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
     for (int it = 0; it < iters; ++it) {
@@ -44,6 +48,11 @@ __global__ void __launch_bounds__(1024) k_valu(float *out, unsigned long long *s
     else if (KIND == 8) asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x)); \
     else if (KIND == 9) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "+v"(a[i]) : "v"(b), "v"(c)); \
     else if (KIND == 10) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(c.y));                           \
+    else if (KIND == 12) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x), "s"(smask)); \
+    else if (KIND == 13) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(b.x), "v"(a[(i + 8) & 15].y)); \
+    else if (KIND == 14) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y)); \
+    else if (KIND == 15) asm volatile("v_cndmask_b32_e64 %0, %1, -%2, %3" : "+v"(a[i].x) : "v"(a[(i + 8) & 15].y), "v"(b.x), "s"(smask)); \
+    else if (KIND == 16) asm volatile("v_swap_b32 %0, %1" : "+v"(a[i].x), "+v"(a[i].y)); \
     else if (KIND == 11) { asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].x) : "v"(b.x), "v"(c.x)); asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i].y) : "v"(b.y), "v"(c.y)); }
             REP16(ONE)
 #undef ONE
@@ -66,7 +75,7 @@ template <int KIND>
 __global__ void __launch_bounds__(1024) k_lds(float *out, unsigned long long *stamps, int iters, float seed) {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) lds[i] = seed + i;
+    for (int i = threadIdx.x; i < 16 * 1024; i += blockDim.x) lds[i] = __builtin_bit_cast(float, 0x3f000000u | (((i + blockIdx.x * 7919u) * 2654435761u) >> 9)) * seed;
     __syncthreads();
     const unsigned base = (unsigned)(wave * 1024 * 4 + lane * (KIND == 1 ? 16 : (KIND == 0 || KIND == 2 ? 8 : 4)));
     float r[4] = {seed, seed, seed, seed};
@@ -95,6 +104,8 @@ __global__ void __launch_bounds__(1024) k_lds(float *out, unsigned long long *st
         stamps[2 * w + 1] = r1 - r0;
     }
 }
+
+static const size_t LDSB = 100 * 1024;   // > half of the CU's 160 KiB: one workgroup per CU
 
 template <class K>
 static void run(const char *name, K kernel, int waves_per_simd, int instr_per_iter, int iters, size_t lds_bytes,
@@ -127,17 +138,70 @@ static void run(const char *name, K kernel, int waves_per_simd, int instr_per_it
     CHECK(hipEventDestroy(e1));
 }
 
-static const size_t LDSB = 100 * 1024;   // > half of the CU's 160 KiB: one workgroup per CU
+template <class K>
+static void sustain(const char *name, K kernel, int wps, int instr_per_iter, double seconds, float *out, unsigned long long *stamps_d) {
+    const int threads = 256 * wps, blocks = 256, iters = 20000;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDSB));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0, 0));
+    int launches = 0;
+    float ms = 0;
+    do {
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), LDSB, 0, out, stamps_d, iters, 1.0f);
+        launches += 10;
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+    } while (ms < seconds * 1e3);
+    std::vector<unsigned long long> st(2 * blocks * threads / 64);
+    CHECK(hipMemcpy(st.data(), stamps_d, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (size_t i = 0; i < st.size() / 2; ++i) if (st[2 * i + 1]) ghz.push_back((double)st[2 * i] / ((double)st[2 * i + 1] * 10.0));
+    std::sort(ghz.begin(), ghz.end());
+    const double winstr = (double)launches * iters * instr_per_iter * blocks * (threads / 64);
+    std::printf("%s waves/SIMD %d: %.3e wave-instructions in %.1f ms = %.3e per second, clock %.3f GHz\n", name, wps, winstr, ms,
+                winstr / (ms * 1e-3), ghz[ghz.size() / 2]);
+}
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc >= 6 && std::string(argv[1]) == "power") {
+        float *out;
+        unsigned long long *stamps;
+        CHECK(hipMalloc(&out, 256 * 1024 * sizeof(float)));
+        CHECK(hipMalloc(&stamps, 2 * 256 * 16 * sizeof(unsigned long long)));
+        const std::string what = argv[2];
+        const int kind = std::atoi(argv[3]), wps = std::atoi(argv[4]);
+        const double sec = std::atof(argv[5]);
+        if (what == "valu") {
+            if (kind == 0) sustain("v_fma_f32", k_valu<0>, wps, 64, sec, out, stamps);
+            else if (kind == 1) sustain("v_pk_fma_f32", k_valu<1>, wps, 64, sec, out, stamps);
+            else if (kind == 2) sustain("v_pk_add_f32", k_valu<2>, wps, 64, sec, out, stamps);
+            else if (kind == 3) sustain("v_pk_mul_f32", k_valu<3>, wps, 64, sec, out, stamps);
+            else if (kind == 4) sustain("v_mov_b32_dpp", k_valu<4>, wps, 64, sec, out, stamps);
+            else if (kind == 5) sustain("v_fmac_f32_dpp", k_valu<5>, wps, 64, sec, out, stamps);
+            else if (kind == 6) sustain("v_add_f32", k_valu<6>, wps, 64, sec, out, stamps);
+            else if (kind == 14) sustain("v_mov_b32", k_valu<14>, wps, 64, sec, out, stamps);
+            else if (kind == 11) sustain("2x v_fma_f32", k_valu<11>, wps, 128, sec, out, stamps);
+        } else {
+            if (kind == 0) sustain("ds_read_b64", k_lds<0>, wps, 16, sec, out, stamps);
+            else if (kind == 1) sustain("ds_read_b128", k_lds<1>, wps, 16, sec, out, stamps);
+            else if (kind == 2) sustain("ds_write_b64", k_lds<2>, wps, 16, sec, out, stamps);
+            else if (kind == 3) sustain("ds_write_b32", k_lds<3>, wps, 16, sec, out, stamps);
+            else if (kind == 4) sustain("ds_read_b32", k_lds<4>, wps, 16, sec, out, stamps);
+        }
+        return 0;
+    }
     float *out;
     unsigned long long *stamps;
     CHECK(hipMalloc(&out, 256 * 1024 * sizeof(float)));
     CHECK(hipMalloc(&stamps, 2 * 256 * 16 * sizeof(unsigned long long)));
     const int iters = 2000;
     const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_mov_b32_dpp", "v_fmac_f32_dpp",
-                           "v_add_f32", "v_cndmask_b32", "v_add_f32_dpp", "v_pk_fma_f32 op_sel/neg", "v_mul_f32", "2x v_fma_f32 (x,y)"};
-    for (int wps = 1; wps <= 4; ++wps) {
+                           "v_add_f32", "v_cndmask_b32 vcc", "v_add_f32_dpp", "v_pk_fma_f32 op_sel/neg", "v_mul_f32", "2x v_fma_f32 (x,y)",
+                           "v_cndmask_b32_e64 sgpr", "v_bfi_b32", "v_mov_b32", "v_cndmask_e64 neg", "v_swap_b32"};
+    for (int wps = 2; wps <= 3; ++wps) {
         run(names[0], k_valu<0>, wps, 64, iters, LDSB, out, stamps);
         run(names[1], k_valu<1>, wps, 64, iters, LDSB, out, stamps);
         run(names[2], k_valu<2>, wps, 64, iters, LDSB, out, stamps);
@@ -150,6 +214,11 @@ int main() {
         run(names[9], k_valu<9>, wps, 64, iters, LDSB, out, stamps);
         run(names[10], k_valu<10>, wps, 64, iters, LDSB, out, stamps);
         run(names[11], k_valu<11>, wps, 128, iters, LDSB, out, stamps);
+        run(names[12], k_valu<12>, wps, 64, iters, LDSB, out, stamps);
+        run(names[13], k_valu<13>, wps, 64, iters, LDSB, out, stamps);
+        run(names[14], k_valu<14>, wps, 64, iters, LDSB, out, stamps);
+        run(names[15], k_valu<15>, wps, 64, iters, LDSB, out, stamps);
+        run(names[16], k_valu<16>, wps, 64, iters, LDSB, out, stamps);
         std::printf("\n");
     }
     const char *lnames[] = {"ds_read_b64", "ds_read_b128", "ds_write_b64", "ds_write_b32", "ds_read_b32", "ds_bpermute_b32"};
