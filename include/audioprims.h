@@ -305,6 +305,59 @@ int ap_db_dct_f32(const float *S /*dev*/, const float *C /*dev (n_out,n_in)*/,
                   float top_db, uint32_t *ws_dev, int max_ready /* *ws_dev already holds max(S) */,
                   float *out /*dev*/, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * Callers that sit directly on the STFT / on the frames.
+ * ---------------------------------------------------------------------- */
+
+/* spectral_centroid / spectral_bandwidth / spectral_rolloff / spectral_flatness —
+ * features.py:57-442, bindings.cpp:371-484 (spectral.cpp:8-257).  One pass over a spectrogram
+ * S (B, F, T): real magnitudes (is_complex = 0) or the complex STFT (is_complex = 1: |X| is taken
+ * on load); `power` raises it (features.py:52-54).  Outputs are (B, T) rows; NULL = not wanted.
+ *   centroid  = sum(f S) / (sum S + 1e-10)
+ *   bandwidth = (sum(S |f - c|^p) / (sum S + 1e-10))^(1/p)   (norm = 0: without the normaliser);
+ *               c = centroid_in (B, T) when given, else the centroid above
+ *   rolloff   = freq of the first bin whose running sum of S reaches roll_percent * sum S
+ *   flatness  = exp(mean log max(S, amin)) / (mean max(S, amin) + 1e-10) */
+int ap_spectral_stats_f32(const float *S /*dev*/, int is_complex, int64_t B, int64_t F, int64_t T,
+                          const float *freq /*dev (F)*/, float power, const float *centroid_in /*dev or NULL*/,
+                          float p, int norm, float roll_percent, float amin, float *centroid /*dev or NULL*/,
+                          float *bandwidth, float *rolloff, float *flatness, void *stream);
+
+/* rms(y, frame_length, hop_length, center, pad_mode) and zero_crossing_rate(...) —
+ * framing.py:81-150, features.py:598-722: per frame sqrt(mean x^2) and the fraction of samples
+ * i >= 1 of the frame with (x[i] >= 0) != (x[i-1] >= 0).  pad = frame_length / 2 if center else 0,
+ * pad_mode AP_PAD_CONSTANT or AP_PAD_EDGE; T = 1 + (L + 2 pad - frame_length) / hop.  Outputs (B, T). */
+int ap_frame_stats_f32(const float *y /*dev (B,L)*/, int64_t B, int64_t L, int frame_length, int hop,
+                       int center, int pad_mode, int64_t T, float *rms /*dev or NULL*/,
+                       float *zcr /*dev or NULL*/, void *stream);
+
+/* preemphasis(y, coef, zi) — framing.py:154-296: out[n] = y[n] - coef y[n-1], out[0] = y[0] + zi[b]
+ * (zi == NULL: 2 y[0] - y[1]); zf[b] = y[L-1] (NULL = not wanted). */
+int ap_preemphasis_f32(const float *y /*dev (B,L)*/, int64_t B, int64_t L, float coef,
+                       const float *zi /*dev (B) or NULL*/, float *out /*dev*/, float *zf /*dev (B) or NULL*/,
+                       void *stream);
+
+/* deemphasis(y, coef, zi) — framing.py:298-392 (scipy.signal.lfilter([1], [1, -coef])):
+ * out[n] = y[n] + coef out[n-1], out[0] = y[0] + zi[b].  zi == NULL: zero state and the reference's
+ * correction ((2-coef) y[0] - y[1]) / (3-coef) * coef^n subtracted.  zf[b] = coef * out[L-1] of the
+ * uncorrected recursion (lfilter's final state). */
+int ap_deemphasis_f32(const float *y /*dev (B,L)*/, int64_t B, int64_t L, float coef,
+                      const float *zi /*dev (B) or NULL*/, float *out /*dev*/, float *zf /*dev (B) or NULL*/,
+                      void *stream);
+
+/* delta(data, width, order, axis, mode) — mfcc.py:290-368 = scipy.signal.savgol_filter: FIR along the
+ * middle axis of x viewed as (outer, n, inner); taps (width) in correlation order; mode AP_SG_*;
+ * edge: (2 * (width/2), width) rows for mode AP_SG_INTERP (polynomial fit of the first / last
+ * `width` samples), else NULL. */
+#define AP_SG_INTERP 0
+#define AP_SG_NEAREST 1
+#define AP_SG_MIRROR 2
+#define AP_SG_CONSTANT 3
+#define AP_SG_WRAP 4
+int ap_savgol_f32(const float *x /*dev*/, int64_t outer, int64_t n, int64_t inner, const float *taps /*dev*/,
+                  int width, int mode, float cval, const float *edge /*dev or NULL*/, float *out /*dev*/,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

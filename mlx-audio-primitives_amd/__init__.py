@@ -8,9 +8,12 @@ kernel behind the C ABI in include/audioprims.h.  There is no CPU fallback.
 from ._extension import HAS_HIP_EXT, _ext
 from ._validation import validate_non_negative, validate_positive, validate_range
 from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
+from .features import (spectral_bandwidth, spectral_centroid, spectral_features, spectral_flatness,
+                       spectral_rolloff, zero_crossing_rate)
+from .framing import deemphasis, frame, preemphasis, rms
 from .griffinlim import griffinlim
 from .mel import hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram
-from .mfcc import dct, mfcc
+from .mfcc import dct, delta, mfcc
 from .resample import resample, resample_poly
 from .stft import check_nola, istft, magnitude, phase, stft
 from .windows import get_window
@@ -23,6 +26,8 @@ __all__ = [
     "get_window",
     "hz_to_mel", "mel_to_hz", "mel_filterbank", "melspectrogram",
     "griffinlim", "resample", "resample_poly",
+    "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "spectral_features",
+    "zero_crossing_rate", "frame", "rms", "preemphasis", "deemphasis", "delta",
     "mfcc", "dct", "power_to_db", "db_to_power", "amplitude_to_db", "db_to_amplitude",
     "validate_positive", "validate_non_negative", "validate_range",
 ]

@@ -53,6 +53,7 @@ ABI_SYMBOLS = [
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
+    "ap_spectral_stats_f32", "ap_frame_stats_f32", "ap_preemphasis_f32", "ap_deemphasis_f32", "ap_savgol_f32",
 ]
 
 HAS_HIP_EXT: bool = False
@@ -98,6 +99,11 @@ def _declare(lib) -> None:
         "ap_griffinlim_f32": [P, P, L, L, I, I, P, P, I, I, L, L, L, I, F, P, P, P, P, P, P],
         "ap_resample_fft_f32": [P, L, L, L, P, P, P, P, P, P, P],
         "ap_phase_f32": [P, L, P, P],
+        "ap_spectral_stats_f32": [P, I, L, L, L, P, F, P, F, I, F, F, P, P, P, P, P],
+        "ap_frame_stats_f32": [P, L, L, I, I, I, I, L, P, P, P],
+        "ap_preemphasis_f32": [P, L, L, F, P, P, P, P],
+        "ap_deemphasis_f32": [P, L, L, F, P, P, P, P],
+        "ap_savgol_f32": [P, L, L, L, P, I, I, F, P, P, P],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

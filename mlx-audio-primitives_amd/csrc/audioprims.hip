@@ -15,6 +15,7 @@
 #include "kernels_ct.h"
 #include "kernels_wave512.h"
 #include "kernels_mel2048.h"
+#include "kernels_features.h"
 
 static thread_local char g_err[512] = "";
 
@@ -618,6 +619,98 @@ int ap_magnitude_f32(const float *S, int64_t n, float *out, void *stream) {
 
 int ap_phase_f32(const float *S, int64_t n, float *out, void *stream) {
     return ap_complex_unary(S, n, 1, out, stream);
+}
+
+// ---------------------------------------------------------------------- §8(f): features / framing
+int ap_spectral_stats_f32(const float *S, int is_complex, int64_t B, int64_t F, int64_t T, const float *freq,
+                          float power, const float *centroid_in, float p, int norm, float roll_percent, float amin,
+                          float *centroid, float *bandwidth, float *rolloff, float *flatness, void *stream) {
+    if (!S || !freq) AP_FAIL(AP_ERR_INVALID, "spectral features: NULL buffer");
+    if (B <= 0 || F <= 0 || T <= 0)
+        AP_FAIL(AP_ERR_INVALID, "S must be 2D (freq_bins, n_frames) or 3D (batch, freq_bins, n_frames)");
+    if (roll_percent < 0.0f || roll_percent > 1.0f) AP_FAIL(AP_ERR_INVALID, "roll_percent must be between 0 and 1");
+    if (!(p > 0.0f)) AP_FAIL(AP_ERR_INVALID, "p must be positive");
+    if (!centroid && !bandwidth && !rolloff && !flatness) return AP_OK;
+    ApSpectralParams P;
+    P.S = S; P.freq = freq; P.centroid_in = centroid_in;
+    P.centroid = centroid; P.bandwidth = bandwidth; P.rolloff = rolloff; P.flatness = flatness;
+    P.F = F; P.T = T; P.tiles_per_clip = (T + APF_TX - 1) / APF_TX;
+    P.is_complex = is_complex; P.norm = norm;
+    P.power = power; P.p = p; P.roll_percent = roll_percent; P.amin = amin;
+    if (P.tiles_per_clip * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "spectral features: grid too large");
+    hipLaunchKernelGGL(ap_spectral_stats_kernel, dim3((unsigned)(P.tiles_per_clip * B)), dim3(APF_TX * APF_TY), 0,
+                       (hipStream_t)stream, P);
+    return ap_check_launch("ap_spectral_stats_f32");
+}
+
+int ap_frame_stats_f32(const float *y, int64_t B, int64_t L, int frame_length, int hop, int center, int pad_mode,
+                       int64_t T, float *rms, float *zcr, void *stream) {
+    if (!y) AP_FAIL(AP_ERR_INVALID, "frame statistics: NULL buffer");
+    if (frame_length <= 0) AP_FAIL(AP_ERR_INVALID, "frame_length must be positive, got %d", frame_length);
+    if (hop <= 0) AP_FAIL(AP_ERR_INVALID, "hop_length must be positive, got %d", hop);
+    if (pad_mode != AP_PAD_CONSTANT && pad_mode != AP_PAD_EDGE)
+        AP_FAIL(AP_ERR_INVALID, "Unknown pad_mode. Supported: 'constant', 'edge'");
+    if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "frame statistics: signal must be non-empty");
+    const int pad = center ? frame_length / 2 : 0;
+    const int64_t Lp = L + 2 * (int64_t)pad;
+    if (Lp < frame_length)
+        AP_FAIL(AP_ERR_INVALID, "Signal length (%lld) must be >= frame_length (%d). Consider padding the signal.",
+                (long long)Lp, frame_length);
+    if (T != 1 + (Lp - frame_length) / hop)
+        AP_FAIL(AP_ERR_INVALID, "frame statistics: n_frames mismatch (got %lld)", (long long)T);
+    if (!rms && !zcr) return AP_OK;
+    // frames per workgroup: the contiguous span (G - 1) hop + frame_length has to fit 64 KiB of LDS
+    const int64_t budget = 16 * 1024;
+    if (frame_length > 36 * 1024) AP_FAIL(AP_ERR_UNSUPPORTED, "frame_length %d does not fit LDS", frame_length);
+    int64_t G = frame_length >= budget ? 1 : (budget - frame_length) / hop + 1;
+    if (G > 64) G = 64;
+    if (G > T) G = T;
+    ApFrameStatsParams P;
+    P.y = y; P.rms = rms; P.zcr = zcr; P.L = L; P.T = T;
+    P.frame_length = frame_length; P.hop = hop; P.pad = pad; P.pad_mode = pad_mode; P.G = (int)G;
+    P.tiles_per_clip = (T + G - 1) / G;
+    if (P.tiles_per_clip * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "frame statistics: grid too large");
+    const int lds = (int)(((G - 1) * hop + frame_length) * sizeof(float));
+    int rc = ap_allow_lds(ap_frame_stats_kernel, lds);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_frame_stats_kernel, dim3((unsigned)(P.tiles_per_clip * B)), dim3(AP_BLOCK), lds,
+                       (hipStream_t)stream, P);
+    return ap_check_launch("ap_frame_stats_f32");
+}
+
+int ap_preemphasis_f32(const float *y, int64_t B, int64_t L, float coef, const float *zi, float *out, float *zf,
+                       void *stream) {
+    if (!y || !out) AP_FAIL(AP_ERR_INVALID, "preemphasis: NULL buffer");
+    if (!(coef >= 0.0f && coef <= 1.0f)) AP_FAIL(AP_ERR_INVALID, "coef must be in [0, 1], got %g", (double)coef);
+    if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "preemphasis: signal must be non-empty");
+    hipLaunchKernelGGL(ap_preemphasis_kernel, dim3(ap_grid_1d(B * L, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, y, B, L, coef, zi, out, zf);
+    return ap_check_launch("ap_preemphasis_f32");
+}
+
+int ap_deemphasis_f32(const float *y, int64_t B, int64_t L, float coef, const float *zi, float *out, float *zf,
+                      void *stream) {
+    if (!y || !out) AP_FAIL(AP_ERR_INVALID, "deemphasis: NULL buffer");
+    if (!(coef >= 0.0f && coef <= 1.0f)) AP_FAIL(AP_ERR_INVALID, "coef must be in [0, 1], got %g", (double)coef);
+    if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "deemphasis: signal must be non-empty");
+    if (B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "deemphasis: grid too large");
+    hipLaunchKernelGGL(ap_deemphasis_kernel, dim3((unsigned)B), dim3(AP_BLOCK), 0, (hipStream_t)stream, y, L, coef, zi,
+                       zi ? 0 : 1, out, zf);
+    return ap_check_launch("ap_deemphasis_f32");
+}
+
+int ap_savgol_f32(const float *x, int64_t outer, int64_t n, int64_t inner, const float *taps, int width, int mode,
+                  float cval, const float *edge, float *out, void *stream) {
+    if (!x || !taps || !out) AP_FAIL(AP_ERR_INVALID, "delta: NULL buffer");
+    if (width < 3) AP_FAIL(AP_ERR_INVALID, "width must be >= 3, got %d", width);
+    if (width % 2 == 0) AP_FAIL(AP_ERR_INVALID, "width must be odd, got %d", width);
+    if (mode < AP_SG_INTERP || mode > AP_SG_WRAP) AP_FAIL(AP_ERR_INVALID, "delta: unknown mode");
+    if (outer <= 0 || n <= 0 || inner <= 0) AP_FAIL(AP_ERR_INVALID, "delta: empty array");
+    if (mode == AP_SG_INTERP && (!edge || width > n))
+        AP_FAIL(AP_ERR_INVALID, "when mode='interp', width=%d cannot exceed data.shape[axis]=%lld", width, (long long)n);
+    hipLaunchKernelGGL(ap_savgol_kernel, dim3(ap_grid_1d(outer * n * inner, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, x, outer, n, inner, taps, width, mode, cval, edge, out);
+    return ap_check_launch("ap_savgol_f32");
 }
 
 }  // extern "C"

@@ -1,0 +1,307 @@
+// Callers that sit directly on the STFT or on the frames: spectral
+// centroid / bandwidth / rolloff / flatness over a (B, F, T) spectrogram, RMS and zero-crossing
+// rate over the frames of a signal, pre- / de-emphasis and the Savitzky-Golay delta filter.
+// All of them are HBM-streaming kernels: every input element is read from HBM once (second passes
+// hit L2 / LDS), outputs are (B, 1, T) rows or arrays of the input's size.
+//
+// Reference: features.py:57-442,598-722; framing.py:81-392; mfcc.py:290-368;
+// native mirrors csrc/primitives/spectral.cpp:8-257.
+#pragma once
+#include "kernels_generic.h"
+
+// ---------------------------------------------------------------------------------------
+// Spectral statistics of every frame of S (B, F, T) (T fastest, librosa layout), real magnitudes
+// or complex STFT output (then |X| is taken on load; `power` != 1 raises it, features.py:52-54).
+//
+// A workgroup owns 32 consecutive frames of one clip: thread (tx = frame, ty = one of 8 contiguous
+// bin stripes).  A wave reads two rows x 32 frames = 2 x 128 contiguous bytes per instruction.
+//   pass A: per stripe  sum S, sum f S, sum log(max(S, amin)), sum max(S, amin)   -> LDS -> totals
+//   pass B: sum S |f - centroid|^p per stripe; the stripe whose running sum crosses
+//           roll_percent * total rescans its bins for the first one at or above it (rows come from L2)
+struct ApSpectralParams {
+    const float *S;            // (B, F, T) real, or (B, F, T, 2) complex
+    const float *freq;         // (F)
+    const float *centroid_in;  // optional (B, T): bandwidth around a given centroid
+    float *centroid, *bandwidth, *rolloff, *flatness;      // (B, T) each, any may be NULL
+    int64_t F, T, tiles_per_clip;
+    int is_complex, norm;
+    float power, p, roll_percent, amin;
+};
+
+#define APF_TX 32
+#define APF_TY 8
+
+AP_DEV float apf_load_mag(const ApSpectralParams &P, const float *Sb, int64_t k, int64_t t) {
+    float v;
+    if (P.is_complex) {
+        const ap_float2 z = reinterpret_cast<const ap_float2 *>(Sb)[k * P.T + t];
+        v = sqrtf(z.x * z.x + z.y * z.y);
+    } else {
+        v = Sb[k * P.T + t];
+    }
+    if (P.power != 1.0f) v = P.power == 2.0f ? v * v : powf(v, P.power);
+    return v;
+}
+
+__global__ void __launch_bounds__(APF_TX * APF_TY) ap_spectral_stats_kernel(ApSpectralParams P) {
+    __shared__ float red[5][APF_TY][APF_TX];
+    const int tx = threadIdx.x & (APF_TX - 1), ty = threadIdx.x / APF_TX;
+    const int64_t b = blockIdx.x / P.tiles_per_clip;
+    const int64_t t = (blockIdx.x - b * P.tiles_per_clip) * APF_TX + tx;
+    const bool live = t < P.T;
+    const float *Sb = P.S + b * P.F * P.T * (P.is_complex ? 2 : 1);
+    const int64_t per = (P.F + APF_TY - 1) / APF_TY;
+    const int64_t k0 = ty * per, k1 = k0 + per < P.F ? k0 + per : P.F;
+
+    float s0 = 0.0f, s1 = 0.0f, sl = 0.0f, sa = 0.0f;
+    if (live) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const float v = apf_load_mag(P, Sb, k, t);
+            s0 += v;
+            s1 = fmaf(P.freq[k], v, s1);
+            const float c = fmaxf(v, P.amin);
+            sl += logf(c);
+            sa += c;
+        }
+    }
+    red[0][ty][tx] = s0; red[1][ty][tx] = s1; red[2][ty][tx] = sl; red[3][ty][tx] = sa;
+    __syncthreads();
+    float tot = 0.0f, tf = 0.0f, tl = 0.0f, ta = 0.0f, before = 0.0f;
+#pragma unroll
+    for (int j = 0; j < APF_TY; ++j) {
+        if (j == ty) before = tot;             // running sum of S at the start of this stripe
+        tot += red[0][j][tx]; tf += red[1][j][tx]; tl += red[2][j][tx]; ta += red[3][j][tx];
+    }
+    const float cen = P.centroid_in ? (live ? P.centroid_in[b * P.T + t] : 0.0f) : tf / (tot + 1e-10f);
+    if (live && ty == 0) {
+        if (P.centroid) P.centroid[b * P.T + t] = tf / (tot + 1e-10f);
+        if (P.flatness) P.flatness[b * P.T + t] = expf(tl / (float)P.F) / (ta / (float)P.F + 1e-10f);
+    }
+    if (!P.bandwidth && !P.rolloff) return;
+    // pass B
+    const float thr = tot * P.roll_percent;
+    const bool mine = live && P.rolloff && (before + s0 >= thr) && (ty == 0 || before < thr);   // first stripe that reaches thr
+    float dev = 0.0f, run = before;
+    int64_t found = -1;
+    if (live && (P.bandwidth || mine)) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const float v = apf_load_mag(P, Sb, k, t);
+            if (P.bandwidth) {
+                const float d = fabsf(P.freq[k] - cen);
+                dev = fmaf(v, P.p == 2.0f ? d * d : powf(d, P.p), dev);
+            }
+            run += v;
+            if (mine && found < 0 && run >= thr) found = k;
+        }
+    }
+    if (mine) P.rolloff[b * P.T + t] = P.freq[found < 0 ? k1 - 1 : found];
+    // a frame whose sums never reach thr (NaNs) keeps argmax's answer: bin 0
+    if (live && P.rolloff && ty == 0 && !(tot >= thr)) P.rolloff[b * P.T + t] = P.freq[0];
+    if (P.bandwidth) {
+        red[4][ty][tx] = dev;
+        __syncthreads();
+        if (live && ty == 0) {
+            float w = 0.0f;
+#pragma unroll
+            for (int j = 0; j < APF_TY; ++j) w += red[4][j][tx];
+            if (P.norm) w = w / (tot + 1e-10f);
+            P.bandwidth[b * P.T + t] = P.p == 2.0f ? sqrtf(w) : powf(w, 1.0f / P.p);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// RMS energy and zero-crossing rate of every frame (framing.py:81-150, features.py:598-722):
+// frames of frame_length samples every hop, constant / edge padding by `pad` on both sides.
+// A workgroup stages the contiguous span of G frames in LDS once (pad remap in the loader); wave w
+// then reduces frames w, w + 4, ... with 64 lanes striding the frame.
+//   zcr: a crossing at sample i >= 1 of the frame when (x[i] >= 0) != (x[i-1] >= 0); mean over
+//        frame_length (the first sample never counts)
+struct ApFrameStatsParams {
+    const float *y;            // (B, L)
+    float *rms, *zcr;          // (B, T), either may be NULL
+    int64_t L, T, tiles_per_clip;
+    int frame_length, hop, pad, pad_mode, G;
+};
+
+__global__ void __launch_bounds__(AP_BLOCK) ap_frame_stats_kernel(ApFrameStatsParams P) {
+    float *span = reinterpret_cast<float *>(ap_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x / P.tiles_per_clip;
+    const int64_t t0 = (blockIdx.x - b * P.tiles_per_clip) * P.G;
+    const int Gt = (int)((P.T - t0) < P.G ? (P.T - t0) : P.G);
+    const float *yb = P.y + b * P.L;
+    const int64_t base = t0 * P.hop - P.pad;
+    const int n_span = (Gt - 1) * P.hop + P.frame_length;
+    for (int i = tid; i < n_span; i += AP_BLOCK) span[i] = ap_load_padded(yb, P.L, base + i, P.pad_mode);
+    __syncthreads();
+    for (int g = wave; g < Gt; g += AP_BLOCK / 64) {
+        const float *fr = span + g * P.hop;
+        float ss = 0.0f;
+        int nc = 0;
+        for (int i = lane; i < P.frame_length; i += 64) {
+            const float x = fr[i];
+            ss = fmaf(x, x, ss);
+            if (i > 0) nc += ((x >= 0.0f) != (fr[i - 1] >= 0.0f)) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ss += __shfl_xor(ss, off, 64);
+            nc += __shfl_xor(nc, off, 64);
+        }
+        if (lane == 0) {
+            if (P.rms) P.rms[b * P.T + t0 + g] = sqrtf(ss / (float)P.frame_length);
+            if (P.zcr) P.zcr[b * P.T + t0 + g] = (float)nc / (float)P.frame_length;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pre-emphasis (framing.py:154-296): out[n] = y[n] - coef y[n-1]; out[0] = y[0] + zi, zi = the
+// caller's initial state or 2 y[0] - y[1]; zf = y[L-1].
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_preemphasis_kernel(const float *y, int64_t B, int64_t L, float coef, const float *zi, float *out, float *zf) {
+    const int64_t n = B * L, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int64_t b = e / L, i = e - b * L;
+        const float x = y[e];
+        float o;
+        if (i == 0) {
+            const float z = zi ? zi[b] : (L > 1 ? 2.0f * x - y[e + 1] : x);
+            o = x + z;
+        } else {
+            o = x - coef * y[e - 1];
+        }
+        out[e] = o;
+        if (zf && i == L - 1) zf[b] = x;
+    }
+}
+
+// De-emphasis (framing.py:298-392): the recursion out[n] = y[n] + coef out[n-1] (scipy lfilter
+// b = [1], a = [1, -coef]; out[0] = y[0] + zi), one workgroup per clip.  The clip is walked in tiles of
+// 256 x 16 samples: a thread runs the recursion over its 16 consecutive samples from a zero state,
+// the 256 end states are combined with the decay coef^16 per thread (Hillis-Steele scan of the affine
+// maps s -> a s + b in LDS), then every thread adds carry * coef^(j+1) to its samples.
+// librosa_zi != 0 (zi == NULL in the reference): zero initial state and the correction
+// ((2-c) y0 - y1) / (3-c) * c^n subtracted from sample n.  zf = coef * (uncorrected) out[L-1].
+#define APD_PER 16
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_deemphasis_kernel(const float *y, int64_t L, float coef, const float *zi, int librosa_zi, float *out, float *zf) {
+    __shared__ float tile[AP_BLOCK * (APD_PER + 1)];
+    __shared__ float sa[2][AP_BLOCK], sb[2][AP_BLOCK];
+    __shared__ float carry_s;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const float *yb = y + b * L;
+    float *ob = out + b * L;
+    float cp[APD_PER + 1];                       // coef^j
+    cp[0] = 1.0f;
+#pragma unroll
+    for (int j = 1; j <= APD_PER; ++j) cp[j] = cp[j - 1] * coef;
+    const float corr = (librosa_zi && L > 1) ? ((2.0f - coef) * yb[0] - yb[1]) / (3.0f - coef) : 0.0f;
+    if (tid == 0) carry_s = librosa_zi ? 0.0f : (zi ? zi[b] : 0.0f);     // state entering sample 0: out[-1] * coef
+    __syncthreads();
+    for (int64_t base = 0; base < L; base += (int64_t)AP_BLOCK * APD_PER) {
+        // coalesced load; thread tid owns samples [tid * 16, tid * 16 + 16) of the tile (rows padded by 1)
+        for (int i = tid; i < AP_BLOCK * APD_PER; i += AP_BLOCK) {
+            const int64_t n = base + i;
+            tile[(i / APD_PER) * (APD_PER + 1) + (i % APD_PER)] = n < L ? yb[n] : 0.0f;
+        }
+        __syncthreads();
+        float v[APD_PER];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < APD_PER; ++j) {
+            s = fmaf(coef, s, tile[tid * (APD_PER + 1) + j]);       // local recursion from a zero state
+            v[j] = s;
+        }
+        // affine map of this thread's segment: state_out = A state_in + Bv, A = coef^16, Bv = coef * s
+        int cur = 0;
+        sa[0][tid] = cp[APD_PER];
+        sb[0][tid] = coef * s;
+        __syncthreads();
+        for (int off = 1; off < AP_BLOCK; off <<= 1) {              // inclusive scan of map composition
+            float a = sa[cur][tid], bb = sb[cur][tid];
+            if (tid >= off) {
+                const float a0 = sa[cur][tid - off], b0 = sb[cur][tid - off];
+                bb = fmaf(a, b0, bb);
+                a = a * a0;
+            }
+            sa[cur ^ 1][tid] = a;
+            sb[cur ^ 1][tid] = bb;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const float cin = carry_s;                                   // coef * out[base - 1]
+        // state entering this thread's segment = (exclusive prefix map)(cin)
+        const float st = tid == 0 ? cin : fmaf(sa[cur][tid - 1], cin, sb[cur][tid - 1]);
+        const float tile_out = fmaf(sa[cur][AP_BLOCK - 1], cin, sb[cur][AP_BLOCK - 1]);
+        __syncthreads();
+        if (tid == 0) carry_s = tile_out;
+#pragma unroll
+        for (int j = 0; j < APD_PER; ++j) {
+            const int64_t n = base + (int64_t)tid * APD_PER + j;
+            float o = fmaf(st, cp[j], v[j]);                         // + state * coef^j (state already holds one coef)
+            if (zf && n == L - 1) zf[b] = coef * o;                  // lfilter's final state, before the correction
+            if (librosa_zi) o -= corr * powf(coef, (float)n);
+            tile[tid * (APD_PER + 1) + j] = o;
+        }
+        __syncthreads();
+        for (int i = tid; i < AP_BLOCK * APD_PER; i += AP_BLOCK) {
+            const int64_t n = base + i;
+            if (n < L) ob[n] = tile[(i / APD_PER) * (APD_PER + 1) + (i % APD_PER)];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Savitzky-Golay filter along the middle axis of x viewed as (outer, n, inner)
+// (mfcc.py:290-368 -> scipy.signal.savgol_filter(deriv = order, delta = 1)):
+//   out[o, i, r] = sum_j taps[j] x[o, remap(i + j - half), r]
+// with scipy.ndimage's boundary modes for the remap (nearest / mirror / constant / wrap) and, for
+// mode 'interp', the first / last `half` outputs taken from the polynomial fitted to the first / last
+// `width` samples: edge[e][j] applied to those samples (host-built rows, e = 0..2 half - 1).
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_savgol_kernel(const float *x, int64_t outer, int64_t n, int64_t inner, const float *taps, int width, int mode,
+                 float cval, const float *edge, float *out) {
+    const int half = width / 2;
+    const int64_t total = outer * n * inner, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t o = e / (n * inner), rem = e - o * n * inner;
+        const int64_t i = rem / inner, r = rem - i * inner;
+        const float *xb = x + o * n * inner + r;
+        float acc = 0.0f;
+        if (mode == AP_SG_INTERP && (i < half || i >= n - half)) {
+            const bool head = i < half;
+            const float *row = edge + (head ? i : half + (i - (n - half))) * width;
+            const int64_t first = head ? 0 : n - width;
+            for (int j = 0; j < width; ++j) acc = fmaf(row[j], xb[(first + j) * inner], acc);
+        } else {
+            for (int j = 0; j < width; ++j) {
+                int64_t q = i + j - half;
+                float v;
+                if (q >= 0 && q < n) {
+                    v = xb[q * inner];
+                } else if (mode == AP_SG_CONSTANT) {
+                    v = cval;
+                } else {
+                    if (mode == AP_SG_NEAREST) q = q < 0 ? 0 : n - 1;
+                    else if (mode == AP_SG_MIRROR) {                 // d c b | a b c d | c b a
+                        if (n == 1) q = 0;
+                        else {
+                            const int64_t period = 2 * (n - 1);
+                            q = ((q % period) + period) % period;
+                            if (q >= n) q = period - q;
+                        }
+                    } else {                                         // wrap
+                        q = ((q % n) + n) % n;
+                    }
+                    v = xb[q * inner];
+                }
+                acc = fmaf(taps[j], v, acc);
+            }
+        }
+        out[e] = acc;
+    }
+}

@@ -1,5 +1,4 @@
-"""DCT and MFCC — same API as /root/reference/mlx_audio_primitives/mfcc.py (``delta`` is a
-SciPy host call in the reference and outside the hot path).
+"""DCT, MFCC and delta features — same API as /root/reference/mlx_audio_primitives/mfcc.py.
 
 mfcc = fused melspectrogram kernel -> dB kernels (global-max clip) -> DCT contraction
 kernel applied straight to the (B, M, T) layout (no transposes, mfcc.py:265-271), with
@@ -7,6 +6,8 @@ the lifter folded into the DCT epilogue.
 """
 
 from __future__ import annotations
+
+import math
 
 import numpy as np
 import torch
@@ -124,4 +125,87 @@ def _db_dct(S: torch.Tensor, dct_type: int, n_mfcc: int, norm, lift, max_key=Non
                                         B, int(n_in), inner, int(n_mfcc), 10.0, 1e-10, 1.0, None, 80.0,
                                         ws.data_ptr(), int(max_key is not None), _x.ptr(out),
                                         _x.stream_ptr(S.device)))
+    return out
+
+
+# --------------------------------------------------------------------------- delta
+_SG_MODES = {"interp": 0, "nearest": 1, "mirror": 2, "constant": 3, "wrap": 4}
+_sg_cache: dict[tuple, tuple] = {}
+
+
+def _savgol_tables(width: int, polyorder: int, deriv: int, delta_x: float, device):
+    """Correlation-order Savitzky-Golay taps and the (2*half, width) edge rows of mode 'interp', built
+    in float64 the way scipy.signal.savgol_coeffs / _fit_edge do (least-squares polynomial through
+    `width` points, `deriv`-th derivative at the output position) - what the reference's host call
+    scipy.signal.savgol_filter(data, width, deriv=order, polyorder=order) computes (mfcc.py:364-366)."""
+    key = (width, polyorder, deriv, float(delta_x), str(device))
+    hit = _sg_cache.get(key)
+    if hit is not None:
+        return hit
+    if polyorder >= width:
+        raise ValueError("polyorder must be less than window_length.")
+    half = width // 2
+    if deriv > polyorder:
+        taps = np.zeros(width)
+    else:
+        pos = np.arange(-half, half + 1, dtype=np.float64)
+        A = pos[None, :] ** np.arange(polyorder + 1)[:, None]               # (polyorder+1, width)
+        rhs = np.zeros(polyorder + 1)
+        rhs[deriv] = float(math.factorial(deriv)) / (delta_x ** deriv)
+        taps = np.linalg.lstsq(A, rhs, rcond=None)[0]
+    # edges: polynomial fitted to the first / last `width` samples, derivative evaluated at the positions
+    # 0..half-1 (head) and width-half..width-1 (tail); linear in the samples -> one row per output
+    coef = np.polyfit(np.arange(width, dtype=np.float64), np.eye(width), polyorder)   # (polyorder+1, width)
+    rows = []
+    for i in list(range(half)) + list(range(width - half, width)):
+        row = np.empty(width)
+        for j in range(width):
+            pc = np.polyder(coef[:, j], deriv) if deriv > 0 else coef[:, j]
+            row[j] = np.polyval(pc, float(i)) / (delta_x ** deriv)
+        rows.append(row)
+    edge = np.asarray(rows, dtype=np.float64)
+    hit = (torch.from_numpy(taps.astype(np.float32)).to(device),
+           torch.from_numpy(np.ascontiguousarray(edge, dtype=np.float32)).to(device))
+    _sg_cache[key] = hit
+    return hit
+
+
+def delta(data, width: int = 9, order: int = 1, axis: int = -1, mode: str = "interp", **kwargs) -> torch.Tensor:
+    """Delta (derivative) features by Savitzky-Golay filtering (reference mfcc.py:290-368, a
+    scipy.signal.savgol_filter host call there; one FIR kernel along `axis` here).
+
+    ``kwargs``: ``polyorder`` (default = order), ``delta`` (sample spacing), ``cval`` (mode 'constant')."""
+    validate_positive(width, "width")
+    validate_positive(order, "order")
+    if width < 3:
+        raise ValueError(f"width must be >= 3, got {width}")
+    if width % 2 == 0:
+        raise ValueError(f"width must be odd, got {width}")
+    if mode not in _SG_MODES:
+        raise ValueError("mode must be 'mirror', 'constant', 'nearest' 'wrap' or 'interp'.")
+    x = _x.to_device_f32(data)
+    if x.ndim == 0:
+        x = x[None]
+    ax = axis % x.ndim
+    n = x.shape[ax]
+    if mode == "interp" and width > n:
+        raise ValueError(
+            f"when mode='interp', width={width} "
+            f"cannot exceed data.shape[axis]={n}"
+        )
+    kwargs.pop("deriv", None)
+    polyorder = int(kwargs.pop("polyorder", order))
+    delta_x = float(kwargs.pop("delta", 1.0))
+    cval = float(kwargs.pop("cval", 0.0))
+    if kwargs:
+        raise TypeError(f"delta() got unexpected keyword arguments {sorted(kwargs)}")
+    x = x.contiguous()
+    taps, edge = _savgol_tables(int(width), polyorder, int(order), delta_x, x.device)
+    outer = int(np.prod(x.shape[:ax], dtype=np.int64)) if ax > 0 else 1
+    inner = int(np.prod(x.shape[ax + 1:], dtype=np.int64)) if ax + 1 < x.ndim else 1
+    out = torch.empty_like(x)
+    if out.numel():
+        _x.check(_x.dlib(x.device).ap_savgol_f32(_x.ptr(x), outer, int(n), inner, _x.ptr(taps), int(width),
+                                                 _SG_MODES[mode], cval, _x.ptr(edge), _x.ptr(out),
+                                                 _x.stream_ptr(x.device)))
     return out

@@ -1,0 +1,233 @@
+"""GPU parity for the callers that sit directly on the STFT / on the frames (SURVEY.md §8f ranks
+1-2): spectral centroid / bandwidth / rolloff / flatness, zero-crossing rate, frame, rms,
+pre- / de-emphasis and delta — HIP kernels through the C ABI against the CPU oracle.  Mirrors the
+reference's tests/test_features.py, tests/test_framing.py and tests/test_mfcc.py:127-164 (whose
+librosa comparisons are restated in the oracle; librosa itself is absent: pinned by proxy through
+the reference's formulas and SciPy — scipy.signal.savgol_filter / lfilter ARE the reference's
+implementation of delta / deemphasis)."""
+
+import numpy as np
+import pytest
+
+from oracle import audio_oracle as ao
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import mlx_audio_primitives_amd as ap  # noqa: E402
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ spectral features
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (512, 128), (400, 160)])
+def test_spectral_centroid_bandwidth_flatness(random_signal, n_fft, hop):
+    y = dev(random_signal)
+    kw = dict(n_fft=n_fft, hop_length=hop)
+    T = 1 + len(random_signal) // hop
+    c = ap.spectral_centroid(y, sr=22050, **kw)
+    assert c.shape == (1, T) and c.dtype == torch.float32
+    np.testing.assert_allclose(host(c), ao.spectral_centroid(random_signal, sr=22050, **kw), rtol=1e-4, atol=1e-2)
+    for p in (2.0, 1.0, 3.0):
+        np.testing.assert_allclose(host(ap.spectral_bandwidth(y, sr=22050, p=p, **kw)),
+                                   ao.spectral_bandwidth(random_signal, sr=22050, p=p, **kw), rtol=2e-4, atol=1e-2)
+    np.testing.assert_allclose(host(ap.spectral_bandwidth(y, sr=22050, norm=False, **kw)),
+                               ao.spectral_bandwidth(random_signal, sr=22050, norm=False, **kw), rtol=2e-4)
+    for power in (2.0, 1.0):
+        f = host(ap.spectral_flatness(y, power=power, **kw))
+        assert f.shape == (1, T) and (f >= 0).all() and (f <= 1.0 + 1e-6).all()
+        np.testing.assert_allclose(f, ao.spectral_flatness(random_signal, power=power, **kw), rtol=2e-4, atol=1e-6)
+
+
+def _rolloff_agrees(got, want, freq, frac=0.02):
+    """The rolloff is a bin frequency: where the float32 running sum meets the threshold within
+    rounding, another summation order may pick the neighbouring bin.  Allow that for < 2 % of frames."""
+    assert got.shape == want.shape
+    step = freq[1] - freq[0]
+    diff = np.abs(got - want)
+    assert (diff <= step * 1.001).all(), diff.max()
+    assert (diff > 0).mean() <= frac, (diff > 0).mean()
+
+
+@pytest.mark.parametrize("roll_percent", [0.85, 0.5, 0.95, 0.1, 1.0, 0.0])
+def test_spectral_rolloff(random_signal, chirp_signal, roll_percent):
+    freq = ao.fft_frequencies(22050, 2048)
+    for sig in (random_signal, chirp_signal):
+        got = host(ap.spectral_rolloff(dev(sig), sr=22050, roll_percent=roll_percent))
+        _rolloff_agrees(got, ao.spectral_rolloff(sig, sr=22050, roll_percent=roll_percent), freq)
+        assert (got >= 0).all() and (got <= 22050 / 2).all()                  # tests/test_features.py:186-193
+    with pytest.raises(ValueError, match="roll_percent must be"):
+        ap.spectral_rolloff(dev(random_signal), roll_percent=1.5)
+
+
+def test_spectral_features_from_spectrogram_batch_and_given_centroid(batch_signals):
+    y = batch_signals[:, :12000]
+    S = ao.magnitude(ao.stft(y))                                            # (4, 1025, T)
+    Sd = dev(S)
+    c = ap.spectral_centroid(S=Sd, sr=22050)
+    assert c.shape == (4, 1, S.shape[-1])
+    np.testing.assert_allclose(host(c), ao.spectral_centroid(S=S, sr=22050), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(host(ap.spectral_centroid(dev(y), sr=22050)), host(c), rtol=1e-4, atol=1e-2)
+    # unbatched S, custom bin centres, bandwidth around a supplied centroid
+    fr = np.linspace(0, 1.0, 1025).astype(np.float32)
+    np.testing.assert_allclose(host(ap.spectral_centroid(S=Sd[1], freq=dev(fr))), ao.spectral_centroid(S=S[1], freq=fr),
+                               rtol=1e-4, atol=1e-6)
+    cen = np.full((4, 1, S.shape[-1]), 3000.0, np.float32)
+    np.testing.assert_allclose(host(ap.spectral_bandwidth(S=Sd, sr=22050, centroid=dev(cen))),
+                               ao.spectral_bandwidth(S=S, sr=22050, centroid=cen), rtol=2e-4)
+    np.testing.assert_allclose(host(ap.spectral_flatness(S=dev(S ** 2))), ao.spectral_flatness(S=S ** 2), rtol=2e-4, atol=1e-6)
+    # all three from one pass == the three separate calls
+    one = ap.spectral_features(dev(y), sr=22050)
+    assert torch.equal(one["centroid"], ap.spectral_centroid(dev(y), sr=22050))
+    assert torch.equal(one["bandwidth"], ap.spectral_bandwidth(dev(y), sr=22050))
+    assert torch.equal(one["rolloff"], ap.spectral_rolloff(dev(y), sr=22050))
+    with pytest.raises(ValueError, match="Either y"):
+        ap.spectral_centroid()
+
+
+def test_spectral_feature_properties():
+    """tests/test_features.py:89-101,236-259: a chirp's centroid stays inside the band; white noise is
+    flat, a sine is not; a pure tone's centroid sits at the tone."""
+    sr = 22050
+    t = np.arange(sr, dtype=np.float32) / sr
+    tone = np.sin(2 * np.pi * 2000.0 * t).astype(np.float32)
+    c = host(ap.spectral_centroid(dev(tone), sr=sr))[0, 2:-2]
+    assert np.abs(c - 2000.0).max() < 25.0
+    noise = np.random.default_rng(1).standard_normal(sr).astype(np.float32)
+    assert host(ap.spectral_flatness(dev(noise))).mean() > 0.3
+    assert host(ap.spectral_flatness(dev(tone)))[0, 2:-2].mean() < 0.01
+    assert host(ap.spectral_bandwidth(dev(tone), sr=sr))[0, 2:-2].max() < 400.0
+
+
+def test_spectral_stats_large_batch_matches_oracle_subsample():
+    """Headline-shaped batch (64 x 5 s): every tile shape of the statistics kernel incl. the ragged
+    last tile (T = 216 = 6 x 32 + 24)."""
+    g = torch.Generator(device="cuda").manual_seed(6)
+    y = torch.randn((64, 110250), device="cuda", generator=g)
+    f = ap.spectral_features(y, sr=22050)
+    assert f["centroid"].shape == (64, 1, 216)
+    idx = [0, 31, 63]
+    yh = host(y[idx])
+    np.testing.assert_allclose(host(f["centroid"][idx]), ao.spectral_centroid(yh, sr=22050), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(host(f["bandwidth"][idx]), ao.spectral_bandwidth(yh, sr=22050), rtol=2e-4, atol=1e-2)
+    _rolloff_agrees(host(f["rolloff"][idx]), ao.spectral_rolloff(yh, sr=22050), ao.fft_frequencies(22050, 2048))
+
+
+# ------------------------------------------------------------------ frame / rms / zcr
+@pytest.mark.parametrize("frame_length,hop", [(2048, 512), (1024, 256), (512, 128), (400, 160), (100, 33), (3, 1)])
+def test_rms_and_zcr(random_signal, frame_length, hop):
+    y = dev(random_signal)
+    for center in (True, False):
+        for pad_mode in ("constant", "edge"):
+            kw = dict(frame_length=frame_length, hop_length=hop, center=center, pad_mode=pad_mode)
+            r = ap.rms(y, **kw)
+            want = ao.rms(random_signal, **kw)
+            assert r.shape == want.shape
+            np.testing.assert_allclose(host(r), want, rtol=1e-5, atol=1e-7)
+            z = ap.zero_crossing_rate(y, **kw)
+            np.testing.assert_array_equal(host(z), ao.zero_crossing_rate(random_signal, **kw))   # counts: exact
+
+
+def test_rms_zcr_batch_edges_and_errors(batch_signals):
+    y = dev(batch_signals)
+    assert ap.rms(y).shape == (4, 1, 44) and ap.zero_crossing_rate(y).shape == (4, 1, 44)
+    np.testing.assert_allclose(host(ap.rms(y)), ao.rms(batch_signals), rtol=1e-5)
+    np.testing.assert_array_equal(host(ap.zero_crossing_rate(y)), ao.zero_crossing_rate(batch_signals))
+    # a signal with exact zeros and negative zeros: (x >= 0) is the sign test (features.py:607-616)
+    x = np.array([0.0, -0.0, 1.0, -1.0, 0.0, 0.0, -2.0, 3.0] * 40, np.float32)
+    np.testing.assert_array_equal(host(ap.zero_crossing_rate(dev(x), frame_length=16, hop_length=8)),
+                                  ao.zero_crossing_rate(x, frame_length=16, hop_length=8))
+    # high-frequency content crosses often, a constant never (tests/test_features.py:347-360)
+    alt = np.tile(np.array([1.0, -1.0], np.float32), 4000)
+    assert host(ap.zero_crossing_rate(dev(alt), center=False)).min() > 0.99
+    assert host(ap.zero_crossing_rate(dev(np.ones(8000, np.float32)))).max() == 0.0
+    with pytest.raises(ValueError, match="must be positive"):
+        ap.rms(y, frame_length=0)
+    with pytest.raises(ValueError, match="Unknown pad_mode"):
+        ap.rms(y, pad_mode="reflect")
+    with pytest.raises(ValueError, match="must be >= frame_length"):
+        ap.rms(dev(np.zeros(10, np.float32)), frame_length=64, center=False)
+
+
+def test_frame_api(random_signal, batch_signals):
+    f = ap.frame(dev(random_signal), 2048, 512)
+    np.testing.assert_array_equal(host(f), ao.frame(random_signal, 2048, 512))
+    assert ap.frame(dev(batch_signals), 1024, 256).shape == (4, 1 + (22050 - 1024) // 256, 1024)
+    with pytest.raises(ValueError, match="axis must be -1"):
+        ap.frame(dev(random_signal), 2048, 512, axis=0)
+    with pytest.raises(ValueError, match="must be positive"):
+        ap.frame(dev(random_signal), 0, 512)
+
+
+# ------------------------------------------------------------------ pre- / de-emphasis
+@pytest.mark.parametrize("coef", [0.97, 0.5, 0.0, 1.0])
+def test_preemphasis_deemphasis(random_signal, batch_signals, coef):
+    for sig in (random_signal, batch_signals, random_signal[:5], random_signal[:4097]):
+        p, zf = ap.preemphasis(dev(sig), coef=coef, return_zf=True)
+        pw, zfw = ao.preemphasis(sig, coef=coef, return_zf=True)
+        np.testing.assert_allclose(host(p), pw, rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(host(zf), zfw)
+        d, dzf = ap.deemphasis(p, coef=coef, return_zf=True)
+        dw, dzfw = ao.deemphasis(pw, coef=coef, return_zf=True)
+        np.testing.assert_allclose(host(d), dw, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(host(dzf), dzfw, rtol=1e-4, atol=2e-5)
+        if coef < 1.0:
+            np.testing.assert_allclose(host(d), sig, rtol=1e-4, atol=5e-5)     # round trip, tests/test_framing.py:198-209
+
+
+def test_emphasis_with_given_state_and_errors(batch_signals):
+    y = batch_signals[:, :3000]
+    for zi in (0.25, np.array([0.1, -0.2, 0.3, 0.0], np.float32)):
+        np.testing.assert_allclose(host(ap.preemphasis(dev(y), zi=zi)), ao.preemphasis(y, zi=zi), rtol=1e-6, atol=1e-6)
+        d, zf = ap.deemphasis(dev(y), zi=zi, return_zf=True)
+        dw, zfw = ao.deemphasis(y, zi=zi, return_zf=True)
+        np.testing.assert_allclose(host(d), dw, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(host(zf), zfw, rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError, match=r"coef must be in \[0, 1\]"):
+        ap.preemphasis(dev(y), coef=1.5)
+    with pytest.raises(ValueError, match=r"coef must be in \[0, 1\]"):
+        ap.deemphasis(dev(y), coef=-0.1)
+
+
+# ------------------------------------------------------------------ delta
+@pytest.mark.parametrize("width,order", [(9, 1), (9, 2), (5, 1), (3, 1), (7, 2)])
+def test_delta_matches_savgol(random_signal, width, order):
+    M = ao.mfcc(random_signal, n_mfcc=13)                                    # (13, 44)
+    d = ap.delta(dev(M), width=width, order=order)
+    assert d.shape == M.shape
+    np.testing.assert_allclose(host(d), ao.delta(M, width=width, order=order), rtol=1e-4, atol=1e-4)
+    for mode in ("nearest", "mirror", "constant", "wrap"):
+        np.testing.assert_allclose(host(ap.delta(dev(M), width=width, order=order, mode=mode)),
+                                   ao.delta(M, width=width, order=order, mode=mode), rtol=1e-4, atol=1e-4, err_msg=mode)
+    # along another axis, batched input
+    Mb = np.stack([M, 2 * M, -M])
+    np.testing.assert_allclose(host(ap.delta(dev(Mb), width=width, order=order, axis=1)),
+                               ao.delta(Mb, width=width, order=order, axis=1), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(ap.delta(dev(Mb), width=width, order=order)),
+                               ao.delta(Mb, width=width, order=order), rtol=1e-4, atol=1e-4)
+
+
+def test_delta_errors_and_full_frontend(random_signal):
+    M = dev(ao.mfcc(random_signal, n_mfcc=13))
+    with pytest.raises(ValueError, match="width must be >= 3"):
+        ap.delta(M, width=1)
+    with pytest.raises(ValueError, match="width must be odd"):
+        ap.delta(M, width=4)
+    with pytest.raises(ValueError, match="cannot exceed"):
+        ap.delta(M[:, :5], width=9)
+    with pytest.raises(ValueError, match="must be positive"):
+        ap.delta(M, order=0)
+    # the ASR front end of BASELINE config 4 completed on the device: preemphasis -> mfcc -> delta, delta-delta
+    y = random_signal
+    feats = torch.cat([ap.mfcc(ap.preemphasis(dev(y)), n_mfcc=13), ap.delta(ap.mfcc(ap.preemphasis(dev(y)), n_mfcc=13)),
+                       ap.delta(ap.mfcc(ap.preemphasis(dev(y)), n_mfcc=13), order=2)])
+    m = ao.mfcc(ao.preemphasis(y), n_mfcc=13)
+    want = np.concatenate([m, ao.delta(m), ao.delta(m, order=2)])
+    assert feats.shape == (39, 44)
+    np.testing.assert_allclose(host(feats), want, rtol=1e-3, atol=5e-3)

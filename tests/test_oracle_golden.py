@@ -136,3 +136,48 @@ def test_griffinlim_reference_thresholds():
     np.testing.assert_allclose(yr, yr2, atol=1e-5)
     with pytest.raises(ValueError, match="Unknown init"):
         ao.griffinlim(S, init="bogus")
+
+
+# ---------------------------------------------------------------- §8(f) restatements
+def test_oracle_feature_properties_and_scipy_identities():
+    """The reference pins features.py / framing.py against librosa (absent here).  The oracle's
+    restatements are pinned through what needs no librosa: SciPy identities (savgol_filter and
+    lfilter ARE the reference's delta / deemphasis), closed forms, and the range / tone / noise
+    properties the reference's own tests assert (tests/test_features.py:89-101,186-193,227-259,
+    331-360; tests/test_framing.py:131-139,198-209)."""
+    import scipy.signal
+    sr = 22050
+    y = ao.random_signal(sr)
+    t = np.arange(sr, dtype=np.float32) / sr
+    tone = np.sin(2 * np.pi * 2000.0 * t).astype(np.float32)
+    # centroid of a pure tone = the tone; bandwidth small; flatness: noise high, tone low
+    assert np.abs(ao.spectral_centroid(tone, sr=sr)[0, 2:-2] - 2000.0).max() < 25.0
+    assert ao.spectral_bandwidth(tone, sr=sr)[0, 2:-2].max() < 400.0
+    assert ao.spectral_flatness(y).mean() > 0.3 and ao.spectral_flatness(tone)[0, 2:-2].mean() < 0.01
+    # weighted-mean identity against a direct NumPy evaluation
+    S = ao.magnitude(ao.stft(y))
+    f = np.linspace(0, sr / 2, 1025)
+    np.testing.assert_allclose(ao.spectral_centroid(S=S, sr=sr)[0], (f[:, None] * S).sum(0) / S.sum(0), rtol=1e-5)
+    # rolloff: monotone in roll_percent, inside [0, Nyquist], == searchsorted on the running sum
+    r50, r85 = ao.spectral_rolloff(y, sr=sr, roll_percent=0.5), ao.spectral_rolloff(y, sr=sr)
+    assert (r50 <= r85).all() and (r85 <= sr / 2).all() and (r50 >= 0).all()
+    cs = np.cumsum(S.astype(np.float32), axis=0, dtype=np.float32)
+    k = [min(int(np.searchsorted(cs[:, j], np.float32(0.85) * cs[-1, j])), 1024) for j in range(S.shape[1])]
+    np.testing.assert_array_equal(r85[0], f.astype(np.float32)[k])
+    # rms / zcr closed forms
+    np.testing.assert_allclose(ao.rms(np.ones(4096, np.float32), center=False), 1.0)
+    alt = np.tile(np.array([1.0, -1.0], np.float32), 2048)
+    np.testing.assert_allclose(ao.zero_crossing_rate(alt, frame_length=1024, hop_length=512, center=False),
+                               1023.0 / 1024.0)
+    assert ao.zero_crossing_rate(np.ones(4096, np.float32)).max() == 0.0
+    # preemphasis == lfilter([1, -c], [1], zi = 2 y0 - y1) ; deemphasis inverts it
+    c = 0.97
+    want, _ = scipy.signal.lfilter([1.0, -c], [1.0], y.astype(np.float64), zi=[2 * y[0] - y[1]])
+    np.testing.assert_allclose(ao.preemphasis(y, coef=c), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ao.deemphasis(ao.preemphasis(y, coef=c), coef=c), y, rtol=1e-4, atol=2e-5)
+    # delta is savgol_filter itself
+    M = ao.mfcc(y, n_mfcc=13)
+    np.testing.assert_allclose(ao.delta(M), scipy.signal.savgol_filter(M, 9, deriv=1, polyorder=1, axis=-1, mode="interp"),
+                               rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError, match="width must be odd"):
+        ao.delta(M, width=4)
