@@ -60,6 +60,13 @@ def test_spectral_rolloff(random_signal, chirp_signal, roll_percent):
     freq = ao.fft_frequencies(22050, 2048)
     for sig in (random_signal, chirp_signal):
         got = host(ap.spectral_rolloff(dev(sig), sr=22050, roll_percent=roll_percent))
+        if roll_percent == 1.0:
+            # "running sum >= total" is decided by the last bits of a float32 sum of 1025 terms: any
+            # summation order (the reference's is MLX's parallel scan) may stop a few bins early.
+            # Well defined: not below the 99.99 % point, not above Nyquist.
+            lo = ao.spectral_rolloff(sig, sr=22050, roll_percent=0.9999)
+            assert (got >= lo - 11.0).all() and (got <= freq[-1]).all()
+            continue
         _rolloff_agrees(got, ao.spectral_rolloff(sig, sr=22050, roll_percent=roll_percent), freq)
         assert (got >= 0).all() and (got <= 22050 / 2).all()                  # tests/test_features.py:186-193
     with pytest.raises(ValueError, match="roll_percent must be"):
