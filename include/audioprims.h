@@ -358,6 +358,33 @@ int ap_savgol_f32(const float *x /*dev*/, int64_t outer, int64_t n, int64_t inne
                   int width, int mode, float cval, const float *edge /*dev or NULL*/, float *out /*dev*/,
                   void *stream);
 
+/* 16-bit PCM ingest (the reference assumes float arrays already in memory,
+ * README.md:34-38): out = x * scale (scale = 1/32768 for full-scale [-1, 1)). */
+int ap_pcm16_to_f32(const int16_t *x /*dev*/, int64_t n, float scale, float *out /*dev*/, void *stream);
+
+/* melspectrogram straight from 16-bit PCM: same arguments as ap_melspec_max_f32 with y (B, L) int16.
+ * Where the n_fft = 2048 run kernel applies (ap_melspec_pcm16_fused() != 0: constant padding or
+ * center = 0, power 2, n_mels <= 128, even L / hop) the conversion rides on the kernel's sample
+ * loads (half the HBM read bytes, no float copy of the batch); otherwise the samples are first
+ * converted into scratch_f32 (B*L floats, required then) and the float path runs. */
+int ap_melspec_pcm16_fused(int64_t L, int n_fft, int hop, int center, int pad_mode, int n_mels, float power,
+                           const int32_t *desc /*host*/);
+int ap_melspec_pcm16_f32(const int16_t *y /*dev (B,L)*/, int64_t B, int64_t L, int n_fft, int hop,
+                         const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
+                         int64_t T, const float *fb /*dev*/, const int32_t *plan /*dev*/,
+                         const int32_t *desc /*host*/, int n_mels, float power, float *out /*dev*/,
+                         uint32_t *max_key /*dev or NULL*/, float *scratch_f32 /*dev (B,L) or NULL*/, void *stream);
+
+/* autocorrelation(y, max_lag, normalize, center) — pitch.py:16-115, bindings.cpp:224-252
+ * (autocorrelation.cpp:10-84): r = irfft(|rfft(y - mean(y), n_fft)|^2)[:max_lag], divided by
+ * max(r[0], 1e-10) when normalize; n_fft = ap_autocorrelation_nfft(n) = the next power of two
+ * >= 2 n - 1 = N1 * N2 (ap_cfft_split_host).  tw1 / tw2: twiddle tables of the two legs
+ * (ap_twiddle_table_host(N1), (N2)); ws: 4 B n_fft + B floats of scratch; out: (B, max_lag). */
+int64_t ap_autocorrelation_nfft(int64_t n);
+int ap_autocorrelation_f32(const float *y /*dev (B,n)*/, int64_t B, int64_t n, int64_t max_lag, int normalize,
+                           int center, const float *tw1 /*dev*/, const float *tw2 /*dev*/, float *ws /*dev*/,
+                           float *out /*dev*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

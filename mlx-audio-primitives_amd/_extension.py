@@ -54,6 +54,8 @@ ABI_SYMBOLS = [
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
     "ap_spectral_stats_f32", "ap_frame_stats_f32", "ap_preemphasis_f32", "ap_deemphasis_f32", "ap_savgol_f32",
+    "ap_autocorrelation_nfft", "ap_autocorrelation_f32",
+    "ap_pcm16_to_f32", "ap_melspec_pcm16_fused", "ap_melspec_pcm16_f32",
 ]
 
 HAS_HIP_EXT: bool = False
@@ -104,6 +106,10 @@ def _declare(lib) -> None:
         "ap_preemphasis_f32": [P, L, L, F, P, P, P, P],
         "ap_deemphasis_f32": [P, L, L, F, P, P, P, P],
         "ap_savgol_f32": [P, L, L, L, P, I, I, F, P, P, P],
+        "ap_autocorrelation_f32": [P, L, L, L, I, I, P, P, P, P, P],
+        "ap_pcm16_to_f32": [P, L, F, P, P],
+        "ap_melspec_pcm16_fused": [L, I, I, I, I, I, F, P],
+        "ap_melspec_pcm16_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P, P, P],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -113,6 +119,8 @@ def _declare(lib) -> None:
     lib.ap_mel_plan_words.restype = L
     lib.ap_istft_workspace_floats.argtypes = [L, L, I, I, L]
     lib.ap_istft_workspace_floats.restype = L
+    lib.ap_autocorrelation_nfft.argtypes = [L]
+    lib.ap_autocorrelation_nfft.restype = L
 
 
 def _load() -> None:

@@ -50,14 +50,14 @@ static int ap_launch_mel_wave(const ApMelWaveParams &W, int grid, void *stream) 
 }
 
 // n_fft = 2048 run kernel (kernels_mel2048.h)
-template <int PMODE, int HOPJ>
+template <int PMODE, int HOPJ, int IN16>
 static int ap_launch_mel_run_h(const ApMelWaveParams &W, int n_pass, int grid, void *stream) {
-#define AP_RUN_LAUNCH(NP)                                                                          \
-    do {                                                                                           \
-        int rc = ap_allow_lds(ap_mel2048_run_kernel<PMODE, NP, HOPJ>, W.lds_bytes);                \
-        if (rc != AP_OK) return rc;                                                                \
-        hipLaunchKernelGGL((ap_mel2048_run_kernel<PMODE, NP, HOPJ>), dim3(grid), dim3(64 * APM_WAVES), \
-                           W.lds_bytes, (hipStream_t)stream, W);                                   \
+#define AP_RUN_LAUNCH(NP)                                                                                \
+    do {                                                                                                 \
+        int rc = ap_allow_lds(ap_mel2048_run_kernel<PMODE, NP, HOPJ, IN16>, W.lds_bytes);                \
+        if (rc != AP_OK) return rc;                                                                      \
+        hipLaunchKernelGGL((ap_mel2048_run_kernel<PMODE, NP, HOPJ, IN16>), dim3(grid), dim3(64 * APM_WAVES), \
+                           W.lds_bytes, (hipStream_t)stream, W);                                         \
     } while (0)
     if (n_pass == 1) AP_RUN_LAUNCH(1);
     else if (n_pass == 2) AP_RUN_LAUNCH(2);
@@ -66,11 +66,11 @@ static int ap_launch_mel_run_h(const ApMelWaveParams &W, int n_pass, int grid, v
 #undef AP_RUN_LAUNCH
     return ap_check_launch("ap_melspec_f32(run)");
 }
-template <int PMODE>
+template <int PMODE, int IN16 = 0>
 static int ap_launch_mel_run(const ApMelWaveParams &W, int n_pass, int grid, void *stream) {
     // hop = 512: the 1536 samples two consecutive frames share stay in registers
-    return W.hopj == 4 ? ap_launch_mel_run_h<PMODE, 4>(W, n_pass, grid, stream)
-                       : ap_launch_mel_run_h<PMODE, 0>(W, n_pass, grid, stream);
+    return W.hopj == 4 ? ap_launch_mel_run_h<PMODE, 4, IN16>(W, n_pass, grid, stream)
+                       : ap_launch_mel_run_h<PMODE, 0, IN16>(W, n_pass, grid, stream);
 }
 
 static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
@@ -711,6 +711,106 @@ int ap_savgol_f32(const float *x, int64_t outer, int64_t n, int64_t inner, const
     hipLaunchKernelGGL(ap_savgol_kernel, dim3(ap_grid_1d(outer * n * inner, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
                        (hipStream_t)stream, x, outer, n, inner, taps, width, mode, cval, edge, out);
     return ap_check_launch("ap_savgol_f32");
+}
+
+int64_t ap_autocorrelation_nfft(int64_t n) {
+    int64_t N = 1;
+    while (N < 2 * n - 1) N *= 2;
+    return N;
+}
+
+int ap_autocorrelation_f32(const float *y, int64_t B, int64_t n, int64_t max_lag, int normalize, int center,
+                           const float *tw1, const float *tw2, float *ws, float *out, void *stream) {
+    if (!y || !out || !ws || !tw1 || !tw2) AP_FAIL(AP_ERR_INVALID, "autocorrelation: NULL buffer");
+    if (B <= 0 || n <= 0)
+        AP_FAIL(AP_ERR_INVALID, "signal must be 1-dimensional (samples,) or 2-dimensional (batch, samples)");
+    if (max_lag <= 0 || max_lag > n) AP_FAIL(AP_ERR_INVALID, "autocorrelation: max_lag must be in [1, n]");
+    const int64_t N = ap_autocorrelation_nfft(n);
+    int n1, n2;
+    if (ap_cfft_split(N, &n1, &n2) != 0)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "autocorrelation: n_fft %lld does not split into two on-chip legs", (long long)N);
+    if (B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "autocorrelation: grid too large");
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ws);
+    ap_float2 *bufB = bufA + B * N;
+    float *padded = reinterpret_cast<float *>(bufB);           // consumed by leg 1 before leg 2 overwrites it
+    float *mean = ws + 4 * B * N;
+    hipStream_t st = (hipStream_t)stream;
+    if (center) {
+        hipLaunchKernelGGL(ap_row_mean_kernel, dim3((unsigned)B), dim3(AP_BLOCK), 0, st, y, n, mean);
+        int rc = ap_check_launch("ap_row_mean");
+        if (rc != AP_OK) return rc;
+    }
+    hipLaunchKernelGGL(ap_autocorr_pad_kernel, dim3(ap_grid_1d(B * N, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0, st,
+                       y, B, n, N, center ? mean : nullptr, padded);
+    int rc = ap_check_launch("ap_autocorr_pad");
+    if (rc != AP_OK) return rc;
+    ApCfftParams L1, L2;
+    rc = ap_prepare_cfft(L1, L2, padded, bufA, bufB, B, N, n1, n2, tw1, tw2, 0, 1, 0, 1.0f);   // forward, real in
+    if (rc != AP_OK) return rc;
+    rc = ap_launch_cfft_leg(L1, B, stream);
+    if (rc != AP_OK) return rc;
+    rc = ap_launch_cfft_leg(L2, B, stream);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_power_spectrum_kernel, dim3(ap_grid_1d(B * N, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0, st,
+                       bufB, B * N);
+    rc = ap_check_launch("ap_power_spectrum");
+    if (rc != AP_OK) return rc;
+    float *r = reinterpret_cast<float *>(bufB);                 // inverse leg 2 writes the real rows over leg 1's input array
+    rc = ap_prepare_cfft(L1, L2, bufB, bufA, r, B, N, n1, n2, tw1, tw2, 1, 0, 1, (float)(1.0 / (double)N));
+    if (rc != AP_OK) return rc;
+    rc = ap_launch_cfft_leg(L1, B, stream);
+    if (rc != AP_OK) return rc;
+    rc = ap_launch_cfft_leg(L2, B, stream);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_autocorr_finish_kernel, dim3(ap_grid_1d(B * max_lag, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK),
+                       0, st, r, B, N, max_lag, normalize, out);
+    return ap_check_launch("ap_autocorrelation_f32");
+}
+
+int ap_pcm16_to_f32(const int16_t *x, int64_t n, float scale, float *out, void *stream) {
+    if (n < 0 || (n > 0 && (!x || !out))) AP_FAIL(AP_ERR_INVALID, "pcm16_to_f32: bad buffer");
+    if (n == 0) return AP_OK;
+    hipLaunchKernelGGL(ap_pcm16_to_f32_kernel, dim3(ap_grid_1d((n + 7) / 8, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, x, n, scale, out);
+    return ap_check_launch("ap_pcm16_to_f32");
+}
+
+int ap_melspec_pcm16_fused(int64_t L, int n_fft, int hop, int center, int pad_mode, int n_mels, float power,
+                           const int32_t *desc) {
+    if (n_fft != 2048 || power != 2.0f || !desc || !(desc[0] & AP_PLAN_PARTS) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 0;
+    if (center && pad_mode != AP_PAD_CONSTANT) return 0;
+    if ((L & 1) || (hop & 1)) return 0;                  // a dword holds the even-indexed sample and its successor
+    if (n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 0;
+    return std::getenv("AP_MEL2048_WAVE") ? 0 : 1;
+}
+
+int ap_melspec_pcm16_f32(const int16_t *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                         const float *tw, int center, int pad_mode, int64_t T, const float *fb, const int32_t *plan,
+                         const int32_t *desc, int n_mels, float power, float *out, uint32_t *max_key_dev,
+                         float *scratch_f32, void *stream) {
+    if (!y) AP_FAIL(AP_ERR_INVALID, "melspectrogram: NULL buffer");
+    if (ap_melspec_pcm16_fused(L, n_fft, hop, center, pad_mode, n_mels, power, desc)) {
+        ApStftParams P;
+        int rc = ap_prepare_stft(P, reinterpret_cast<const float *>(y), B, L, n_fft, hop, window, tw, center, pad_mode, T);
+        if (rc != AP_OK) return rc;
+        rc = ap_prepare_mel(P, fb, plan, desc, n_mels, power, out);
+        if (rc != AP_OK) return rc;
+        ApMelWaveParams W;
+        int grid = 0, n_pass = 0;
+        if (ap_prepare_mel_run(W, P, B, plan, desc, APM_WAVES, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
+            if (max_key_dev) {
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+                if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+                W.max_key = max_key_dev;
+            }
+            return ap_launch_mel_run<2, 1>(W, n_pass, grid, stream);
+        }
+    }
+    if (!scratch_f32) AP_FAIL(AP_ERR_INVALID, "melspectrogram(int16): this shape needs the float32 scratch buffer");
+    int rc = ap_pcm16_to_f32(y, B * L, 1.0f / 32768.0f, scratch_f32, stream);
+    if (rc != AP_OK) return rc;
+    return ap_melspec_max_f32(scratch_f32, B, L, n_fft, hop, window, tw, center, pad_mode, T, fb, plan, desc, n_mels,
+                              power, out, max_key_dev, stream);
 }
 
 }  // extern "C"

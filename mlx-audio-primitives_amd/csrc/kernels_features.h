@@ -305,3 +305,71 @@ ap_savgol_kernel(const float *x, int64_t outer, int64_t n, int64_t inner, const 
         out[e] = acc;
     }
 }
+
+// ---------------------------------------------------------------------------------------
+// Autocorrelation by the Wiener-Khinchin theorem (pitch.py:16-115, autocorrelation.cpp:10-84):
+// r = irfft(|rfft(y - mean, n_fft)|^2)[:max_lag] / max(r[0], 1e-10), n_fft = next power of two
+// >= 2 n - 1.  The two transforms are the four-step complex FFT of kernels_bigfft.h; these kernels
+// are the glue around them.
+__global__ void __launch_bounds__(AP_BLOCK) ap_row_mean_kernel(const float *y, int64_t n, float *mean) {
+    __shared__ float red[AP_BLOCK];
+    const float *yb = y + (int64_t)blockIdx.x * n;
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += AP_BLOCK) s += yb[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = AP_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[blockIdx.x] = red[0] / (float)n;
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_autocorr_pad_kernel(const float *y, int64_t B, int64_t n, int64_t N, const float *mean, float *padded) {
+    const int64_t total = B * N, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / N, i = e - b * N;
+        padded[e] = i < n ? y[b * n + i] - (mean ? mean[b] : 0.0f) : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(AP_BLOCK) ap_power_spectrum_kernel(ap_float2 *X, int64_t count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+        const ap_float2 z = X[e];
+        X[e] = ap_mk(z.x * z.x + z.y * z.y, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_autocorr_finish_kernel(const float *r, int64_t B, int64_t N, int64_t max_lag, int normalize, float *out) {
+    const int64_t total = B * max_lag, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / max_lag, k = e - b * max_lag;
+        float v = r[b * N + k];
+        if (normalize) v = v / fmaxf(r[b * N], 1e-10f);
+        out[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 16-bit PCM -> float32 (x * scale, scale = 1 / 32768): the ingest step in front of the path
+// (SURVEY.md §8f rank 3).  The n_fft = 2048 mel run kernel converts inside its sample loads instead;
+// this pass serves every other shape.  8 samples (one 16-byte load, two 16-byte stores) per thread.
+__global__ void __launch_bounds__(AP_BLOCK) ap_pcm16_to_f32_kernel(const int16_t *x, int64_t n, float scale, float *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n8 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? n / 8 : 0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += stride) {
+        const ap_int4 d = reinterpret_cast<const ap_int4 *>(x)[e];
+        ap_float4 a, b;
+        a.x = (float)(short)(d.x & 0xFFFF) * scale; a.y = (float)(d.x >> 16) * scale;
+        a.z = (float)(short)(d.y & 0xFFFF) * scale; a.w = (float)(d.y >> 16) * scale;
+        b.x = (float)(short)(d.z & 0xFFFF) * scale; b.y = (float)(d.z >> 16) * scale;
+        b.z = (float)(short)(d.w & 0xFFFF) * scale; b.w = (float)(d.w >> 16) * scale;
+        reinterpret_cast<ap_float4 *>(out)[2 * e] = a;
+        reinterpret_cast<ap_float4 *>(out)[2 * e + 1] = b;
+    }
+    for (int64_t e = 8 * n8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+        out[e] = (float)x[e] * scale;
+}

@@ -228,8 +228,9 @@ AP_DEV void apm_split(const ap_float2 *X, const ApwLane &c, const ap_float2 (&ws
     } while (0)
 #endif
 
-template <int PMODE, int NPASS, int HOPJ, int NW = APM_WAVES, int REGS = APM_REGS>
+template <int PMODE, int NPASS, int HOPJ, int IN16 = 0, int NW = APM_WAVES, int REGS = APM_REGS>
 __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWaveParams P) {
+    static_assert(!IN16 || (REGS & APM_REG_WIN), "the PCM scale rides on the register-resident window");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = AP_UNIFORM(tid >> 6);
@@ -263,6 +264,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         winr[j] = (REGS & APM_REG_WIN) ? reinterpret_cast<const ap_float2 *>(P.window)[lane + 64 * j] : ap_mk(0.0f, 0.0f);
+        if (IN16) winr[j] = ap_scale(winr[j], 1.0f / 32768.0f);      // 16-bit PCM -> [-1, 1): folded into the window
         t1r[j] = (REGS & APM_REG_TW1) ? P.tw[(2 * lane * j) & 2047] : ap_mk(0.0f, 0.0f);        // W_1024^(lane j)
         t2r[j] = (REGS & APM_REG_TW2) ? ap_scale(P.tw[32 * (lane & 3) * j], lm.sg) : ap_mk(0.0f, 0.0f);
     }
@@ -304,14 +306,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
     if (f_lo < f_hi) {
         int64_t b = f_lo / P.T;                   // the only division: (clip, frame) advance incrementally
         int t = (int)(f_lo - b * P.T);
-        ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+        // IN16: P.y points at int16 samples (the ingest conversion rides on the
+        // sample loads; half the HBM read bytes of the float32 path)
+        const int16_t *y16 = reinterpret_cast<const int16_t *>(P.y);
+        ApClip clip = ap_clip_make(P.y + (IN16 ? 0 : b * P.L), IN16 ? 0 : P.L);
+        ApClip16 clip16 = ap_clip16_make(y16 + (IN16 ? b * P.L : 0), IN16 ? P.L : 0);
         ap_float2 raw[16];
         auto load_frame = [&](int tt) {
             const int base = tt * P.hop - P.pad;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int p = base + 2 * (lane + 64 * j);
-                raw[j] = ap_clip_load2(clip, p);
+                raw[j] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
             }
         };
         load_frame(t);
@@ -341,7 +347,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
             AP_SCHED_FENCE();
             if (more) {
                 if (clip_ends) {                  // next clip starts
-                    clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
+                    if (IN16) clip16 = ap_clip16_make(y16 + (b + 1) * P.L, P.L);
+                    else clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
                     load_frame(0);
                 } else if (HOPJ == 0) {
                     load_frame(t + 1);
@@ -352,7 +359,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
 #pragma unroll
                     for (int j = 0; j < 16 - HOPJ; ++j) raw[j] = raw[j + HOPJ];
 #pragma unroll
-                    for (int j = 16 - HOPJ; j < 16; ++j) raw[j] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+                    for (int j = 16 - HOPJ; j < 16; ++j) {
+                        const int p = base + 2 * (lane + 64 * j);
+                        raw[j] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                    }
                 }
             }
             AP_SCHED_FENCE();

@@ -84,6 +84,13 @@ struct ApClip { const float *base; int64_t n; };
 AP_DEV ApClip ap_clip_make(const float *base, int64_t n) { ApClip c; c.base = base; c.n = n; return c; }
 AP_DEV float ap_clip_load(const ApClip &c, int64_t idx) { return (idx >= 0 && idx < c.n) ? c.base[idx] : 0.0f; }
 AP_DEV ap_float2 ap_clip_load2(const ApClip &c, int64_t idx) { return ap_mk(ap_clip_load(c, idx), ap_clip_load(c, idx + 1)); }
+// 16-bit PCM clip: samples idx, idx + 1 as floats (unscaled integers), 0 outside [0, n)
+struct ApClip16 { const int16_t *base; int64_t n; };
+AP_DEV ApClip16 ap_clip16_make(const int16_t *base, int64_t n) { ApClip16 c; c.base = base; c.n = n; return c; }
+AP_DEV ap_float2 ap_clip16_load2(const ApClip16 &c, int64_t idx) {
+    return ap_mk((idx >= 0 && idx < c.n) ? (float)c.base[idx] : 0.0f,
+                 (idx + 1 >= 0 && idx + 1 < c.n) ? (float)c.base[idx + 1] : 0.0f);
+}
 #else
 #define AP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler x is wave-uniform
 // one clip as a raw buffer resource: the hardware range check returns 0 for every sample
@@ -101,6 +108,16 @@ AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
 AP_DEV ap_float2 ap_clip_load2(ApClip c, int idx) {
     typedef int ap_i2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(ap_float2, __builtin_bit_cast(ap_i2, __builtin_amdgcn_raw_buffer_load_b64(c, idx * 4, 0, 0)));
+}
+// 16-bit PCM clip (n even, idx even: the launch code guarantees both): one dword = samples idx, idx + 1,
+// converted to float (unscaled: the 1 / 32768 rides on the window); the hardware range check zero-pads
+typedef __amdgpu_buffer_rsrc_t ApClip16;
+AP_DEV ApClip16 ap_clip16_make(const int16_t *base, int64_t n) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t *>(base), 0, (int)(n * 2), 0x00020000);
+}
+AP_DEV ap_float2 ap_clip16_load2(ApClip16 c, int idx) {
+    const int d = __builtin_amdgcn_raw_buffer_load_b32(c, idx * 2, 0, 0);
+    return ap_mk((float)(short)(d & 0xFFFF), (float)(d >> 16));
 }
 #endif
 

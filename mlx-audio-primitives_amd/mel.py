@@ -57,17 +57,15 @@ def mel_to_hz(mels, htk: bool = False) -> np.ndarray:
     return _MelScale.inverse(np.asarray(mels), htk)
 
 
-@lru_cache(maxsize=64)
-def _triangular_bank(sr, n_fft, n_mels, fmin, fmax, htk, norm) -> np.ndarray:
-    """Dense (n_mels, n_fft//2+1) float32 bank of triangles whose corners are equally spaced on
-    the mel scale.  Bit-compatible with the reference's NumPy builder (mel.py:100-168), whose
-    two quirks are part of the contract: each ramp's denominator carries a +1e-10 guard, and the
-    triangle is rounded to float32 BEFORE the Slaney area normalisation 2 / (f[i+2] - f[i])
-    (a float64 product rounded to float32 once more)."""
+def _triangles(corners: np.ndarray, sr, n_fft: int, norm) -> np.ndarray:
+    """Dense (len(corners) - 2, n_fft//2+1) float32 bank of triangles over the FFT bin centres with
+    corner frequencies `corners` (Hz, ascending): filter i rises from corners[i] to its peak at
+    corners[i+1] and falls to corners[i+2].  Bit-compatible with the reference's NumPy builders
+    (mel.py:100-168, filterbanks.py:113-160,226-265), whose two quirks are part of the contract: each
+    ramp's denominator carries a +1e-10 guard, and the triangle is rounded to float32 BEFORE the
+    Slaney area normalisation 2 / (f[i+2] - f[i]) (a float64 product rounded to float32 once more)."""
     if norm not in ("slaney", None):
         raise ValueError(f"Unknown norm: '{norm}'. Supported: 'slaney', None")
-    corners = mel_to_hz(np.linspace(hz_to_mel(fmin, htk=htk), hz_to_mel(fmax, htk=htk), n_mels + 2),
-                        htk=htk)
     left, peak, right = corners[:-2], corners[1:-1], corners[2:]
     grid = np.linspace(0, sr / 2.0, 1 + n_fft // 2)[np.newaxis, :]
     rising = (grid - left[:, np.newaxis]) / (peak - left + 1e-10)[:, np.newaxis]
@@ -77,6 +75,14 @@ def _triangular_bank(sr, n_fft, n_mels, fmin, fmax, htk, norm) -> np.ndarray:
         np.multiply(bank, (2.0 / (right - left))[:, np.newaxis], out=bank, casting="same_kind")
     bank.setflags(write=False)
     return bank
+
+
+@lru_cache(maxsize=64)
+def _triangular_bank(sr, n_fft, n_mels, fmin, fmax, htk, norm) -> np.ndarray:
+    """Mel filterbank: triangles whose corners are equally spaced on the mel scale (mel.py:100-168)."""
+    corners = mel_to_hz(np.linspace(hz_to_mel(fmin, htk=htk), hz_to_mel(fmax, htk=htk), n_mels + 2),
+                        htk=htk)
+    return _triangles(corners, sr, n_fft, norm)
 
 
 _device_filterbank_cache: dict[tuple, tuple] = {}
@@ -121,8 +127,18 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
 
     Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32.  ``_max_key`` (internal,
     mfcc): a 1-element int32 device tensor that receives the order-preserving key of max(out)."""
+    def bank(dev):
+        return _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
+
+    return _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, _max_key)
+
+
+def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key=None):
+    """bank(dev) -> (dense filterbank (M, F), contraction plan, plan descriptor) on `dev`;
+    returns bank @ |stft(y)|**power from ONE fused kernel launch."""
     hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
-    y = _x.to_device_f32(y)
+    pcm16 = _is_pcm16(y)
+    y = _to_device_pcm16(y) if pcm16 else _x.to_device_f32(y)
     one_d = y.ndim == 1
     if one_d:
         y = y[None, :]
@@ -132,16 +148,82 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
     dev = y.device
     win = _get_padded_window(window, win_length, n_fft, dev)
     T = _frame_count(L, n_fft, hop_length, center, pad_mode)
-    fb, plan, desc = _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
-    out = torch.empty((B, n_mels, T), dtype=torch.float32, device=dev)
+    fb, plan, desc = bank(dev)
+    n_rows = fb.shape[0]
+    out = torch.empty((B, n_rows, T), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
         tw = _get_twiddles(n_fft, dev)
-        _x.check(_x.dlib(dev).ap_melspec_max_f32(
-            _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
-            _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_mels),
-            float(power), _x.ptr(out), None if _max_key is None else _max_key.data_ptr(),
-            _x.stream_ptr(dev)))
+        key_ptr = None if max_key is None else max_key.data_ptr()
+        if pcm16:
+            # 16-bit PCM: converted inside the n_fft=2048 run kernel's loads where
+            # that kernel applies, else by one conversion pass into a float32 scratch copy
+            fused = _x.lib().ap_melspec_pcm16_fused(L, int(n_fft), hop_length, int(bool(center)),
+                                                    _x.PAD_MODES[pad_mode], int(n_rows), float(power),
+                                                    desc.ctypes.data)
+            scratch = None if fused else torch.empty((B, L), dtype=torch.float32, device=dev)
+            _x.check(_x.dlib(dev).ap_melspec_pcm16_f32(
+                _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
+                _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_rows),
+                float(power), _x.ptr(out), key_ptr, None if scratch is None else _x.ptr(scratch),
+                _x.stream_ptr(dev)))
+        else:
+            _x.check(_x.dlib(dev).ap_melspec_max_f32(
+                _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
+                _x.PAD_MODES[pad_mode], T, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_rows),
+                float(power), _x.ptr(out), key_ptr, _x.stream_ptr(dev)))
     else:
         out.zero_()
-        _max_key = None
     return out[0] if one_d else out
+
+
+def _is_pcm16(y) -> bool:
+    return (isinstance(y, torch.Tensor) and y.dtype == torch.int16) or \
+        (isinstance(y, np.ndarray) and y.dtype == np.int16)
+
+
+def _to_device_pcm16(y) -> torch.Tensor:
+    """Contiguous int16 tensor in HBM (full scale +-32768 = +-1.0)."""
+    if isinstance(y, torch.Tensor):
+        dev = y.device if y.is_cuda else _x.require_device()
+        _x.lib()
+        return y.to(dev).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(y)).to(_x.require_device())
+
+
+def pcm16_to_float(y) -> torch.Tensor:
+    """int16 PCM -> float32 in [-1, 1) on the device (x / 32768): the ingest step for every operator
+    other than the mel front end, which converts inside its own loads."""
+    y16 = _to_device_pcm16(y)
+    out = torch.empty(y16.shape, dtype=torch.float32, device=y16.device)
+    if y16.numel():
+        _x.check(_x.dlib(y16.device).ap_pcm16_to_f32(_x.ptr(y16), y16.numel(), 1.0 / 32768.0, _x.ptr(out),
+                                                     _x.stream_ptr(y16.device)))
+    return out
+
+
+_custom_bank_cache: dict[tuple, tuple] = {}
+
+
+def filterbank_spectrogram(y, filterbank, n_fft: int = 2048, hop_length: int | None = None,
+                           win_length: int | None = None, window="hann", center: bool = True,
+                           pad_mode: str = "constant", power: float = 2.0) -> torch.Tensor:
+    """filterbank @ |stft(y)|**power for ANY (n_bands, n_fft//2+1) bank - e.g. ``bark_filterbank`` or
+    ``linear_filterbank`` - through the same fused kernels as ``melspectrogram`` (not in the reference,
+    which stops at building those banks, filterbanks.py:163-342)."""
+    fbt = filterbank if isinstance(filterbank, torch.Tensor) else torch.as_tensor(np.asarray(filterbank))
+    fb_np = np.ascontiguousarray(fbt.detach().cpu().numpy(), dtype=np.float32)
+    if fb_np.ndim != 2 or fb_np.shape[1] != 1 + n_fft // 2:
+        raise ValueError(f"filterbank must have shape (n_bands, {1 + n_fft // 2}), got {tuple(fb_np.shape)}")
+
+    def bank(dev):
+        key = (hash(fb_np.tobytes()), fb_np.shape, str(dev))
+        hit = _custom_bank_cache.get(key)
+        if hit is None:
+            plan_np, desc = _x.mel_plan_host(fb_np)
+            hit = (torch.from_numpy(fb_np.copy()).to(dev), torch.from_numpy(plan_np).to(dev), desc)
+            if len(_custom_bank_cache) >= 32:
+                _custom_bank_cache.pop(next(iter(_custom_bank_cache)))
+            _custom_bank_cache[key] = hit
+        return hit
+
+    return _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank)

@@ -76,7 +76,8 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
     max_key = None
     if S is None:
         # the mel kernel also leaves max(S) for the top_db clip of the dB stage (one atomic per wave)
-        y = _x.to_device_f32(y)
+        from .mel import _is_pcm16, _to_device_pcm16
+        y = _to_device_pcm16(y) if _is_pcm16(y) else _x.to_device_f32(y)
         max_key = torch.empty(1, dtype=torch.int32, device=y.device)
         S = melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop_length, win_length=win_length,
                            window=window, center=center, pad_mode=pad_mode, power=power,

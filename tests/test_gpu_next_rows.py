@@ -1,0 +1,151 @@
+"""GPU parity for SURVEY.md §8f ranks 3-4: 16-bit PCM ingest fused ahead of the mel kernel,
+streaming (chunked) STFT / mel, linear / Bark filterbanks through the fused contraction kernels,
+autocorrelation."""
+
+import numpy as np
+import pytest
+
+from oracle import audio_oracle as ao
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import mlx_audio_primitives_amd as ap  # noqa: E402
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ int16 ingest
+def _pcm(shape, seed):
+    rng = np.random.default_rng(seed)
+    return np.clip(rng.standard_normal(shape) * 6000.0, -32768, 32767).astype(np.int16)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128),                    # fused into the run kernel
+    dict(sr=16000, n_fft=2048, hop_length=512, n_mels=80, center=False),       # fused, no centring
+    dict(sr=22050, n_fft=2048, hop_length=300, n_mels=64),                     # fused, full reload per frame
+    dict(sr=16000, n_fft=400, hop_length=160, n_mels=80),                      # conversion pass + ct engine
+    dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128, pad_mode="reflect"),  # conversion pass + tile kernel
+    dict(sr=22050, n_fft=1024, hop_length=256, n_mels=64, power=1.0),
+])
+def test_melspectrogram_from_int16_pcm(kw):
+    x = _pcm((5, 30000), 16)
+    want = ao.melspectrogram(x.astype(np.float32) / 32768.0, **kw)
+    got = ap.melspectrogram(dev(x), **kw)
+    assert got.shape == want.shape and got.dtype == torch.float32
+    np.testing.assert_allclose(host(got), want, rtol=1e-4, atol=1e-6)
+    # identical to converting first (same kernels or the fused conversion: within float32 rounding)
+    via_float = ap.melspectrogram(ap.pcm16_to_float(dev(x)), **kw)
+    np.testing.assert_allclose(host(got), host(via_float), rtol=2e-5, atol=1e-7)
+    # numpy int16 input and a 1-D clip
+    np.testing.assert_allclose(host(ap.melspectrogram(x[0], **kw)), want[0], rtol=1e-4, atol=1e-6)
+
+
+def test_pcm16_edges_and_mfcc():
+    x = _pcm((3, 20001), 7)                                   # odd length: not fusable, conversion pass
+    kw = dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    np.testing.assert_allclose(host(ap.melspectrogram(dev(x), **kw)),
+                               ao.melspectrogram(x.astype(np.float32) / 32768.0, **kw), rtol=1e-4, atol=1e-6)
+    full = np.array([[-32768, 32767, 0, 1, -1] * 2000], np.int16)
+    np.testing.assert_array_equal(host(ap.pcm16_to_float(dev(full))), full.astype(np.float32) / 32768.0)
+    np.testing.assert_array_equal(host(ap.pcm16_to_float(dev(full[0, :7]))), full[0, :7].astype(np.float32) / 32768.0)
+    x2 = _pcm((4, 32000), 8)
+    got = ap.mfcc(dev(x2), sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    want = ao.mfcc(x2.astype(np.float32) / 32768.0, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    np.testing.assert_allclose(host(got), want, rtol=1e-4, atol=2e-3)
+
+
+def test_pcm16_headline_shape_full_scale_property():
+    """Headline-shaped batch: scaling the PCM by 2 (exact in int16 here) scales the power mel by 4."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = (torch.randn((64, 220500), device="cuda", generator=g) * 3000).clamp(-16000, 16000).to(torch.int16)
+    kw = dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    M = ap.melspectrogram(x, **kw)
+    assert M.shape == (64, 128, 431)
+    assert torch.equal(ap.melspectrogram(x * 2, **kw), M * 4.0)
+    np.testing.assert_allclose(host(M[[0, 63]]), ao.melspectrogram(host(x[[0, 63]]).astype(np.float32) / 32768.0, **kw),
+                               rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ streaming
+@pytest.mark.parametrize("n_fft,hop", [(2048, 512), (1024, 256), (400, 160), (512, 500)])
+def test_streaming_stft_equals_offline(n_fft, hop):
+    rng = np.random.default_rng(n_fft)
+    y = rng.standard_normal((3, 40000)).astype(np.float32)
+    whole = ap.stft(dev(y), n_fft=n_fft, hop_length=hop, center=False)
+    st = ap.StreamingSTFT(n_fft=n_fft, hop_length=hop)
+    cuts = [0, 100, 2500, 2501, 9000, 9000 + n_fft, 25000, 40000]           # ragged chunks, one shorter than a hop
+    parts = [st.process(dev(y[:, a:b])) for a, b in zip(cuts[:-1], cuts[1:])]
+    got = torch.cat(parts, dim=-1)
+    assert got.shape == whole.shape and st.frames_emitted == whole.shape[-1]
+    assert torch.equal(torch.view_as_real(got), torch.view_as_real(whole))   # same kernels, same bits
+    assert st.flush().shape[-1] == 0
+    np.testing.assert_allclose(host(got), ao.stft(y, n_fft=n_fft, hop_length=hop, center=False), rtol=1e-4, atol=1e-4)
+
+
+def test_streaming_mel_centered_equals_offline():
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(50000).astype(np.float32)
+    kw = dict(sr=22050, n_mels=80)
+    whole = ap.melspectrogram(dev(y), n_fft=2048, hop_length=512, center=True, **kw)
+    st = ap.StreamingSTFT(n_fft=2048, hop_length=512, center=True, **kw)
+    parts = [st.process(dev(y[a:a + 7000])) for a in range(0, 50000, 7000)] + [st.flush()]
+    got = torch.cat(parts, dim=-1)
+    assert got.shape == whole.shape
+    assert torch.equal(got, whole)
+    st.reset()
+    assert st.process(dev(y[:100])).shape == (80, 0)
+
+
+# ------------------------------------------------------------------ linear / Bark banks
+@pytest.mark.parametrize("which", ["bark", "bark-t", "linear"])
+def test_bark_and_linear_banks_through_the_fused_kernels(random_signal, which):
+    if which == "linear":
+        fb = ap.linear_filterbank(22050, 2048, 64)
+        want_fb = ao.linear_filterbank(22050, 2048, 64)
+    else:
+        formula = "traunmuller" if which == "bark-t" else "zwicker"
+        fb = ap.bark_filterbank(22050, 2048, 24, formula=formula)
+        want_fb = ao.bark_filterbank(22050, 2048, 24, formula=formula)
+    assert fb.is_cuda
+    np.testing.assert_array_equal(host(fb), want_fb)
+    got = ap.filterbank_spectrogram(dev(random_signal), fb, n_fft=2048, hop_length=512)
+    S = ao.magnitude(ao.stft(random_signal)).astype(np.float64) ** 2
+    want = (want_fb.astype(np.float64) @ S).astype(np.float32)
+    np.testing.assert_allclose(host(got), want, rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError, match="cannot exceed Nyquist"):
+        ap.bark_filterbank(22050, 2048, 24, fmax=20000.0)
+    with pytest.raises(ValueError, match="Unknown formula"):
+        ap.hz_to_bark(np.array([100.0]), formula="x")
+
+
+# ------------------------------------------------------------------ autocorrelation
+@pytest.mark.parametrize("n", [22050, 4096, 2205, 1, 5, 70001])
+def test_autocorrelation(n):
+    rng = np.random.default_rng(n)
+    y = rng.standard_normal((3, n)).astype(np.float32) + 0.3
+    for kw in (dict(), dict(normalize=False), dict(center=False), dict(max_lag=min(500, n))):
+        got = ap.autocorrelation(dev(y), **kw)
+        want = ao.autocorrelation(y, **kw)
+        assert got.shape == want.shape
+        scale = np.abs(want).max()
+        np.testing.assert_allclose(host(got), want, rtol=1e-4, atol=1e-4 * max(scale, 1.0))
+    r = host(ap.autocorrelation(dev(y[0])))
+    assert r.shape == (n,) and (n == 1 or np.isclose(r[0], 1.0, rtol=1e-5))
+
+
+def test_autocorrelation_sine_peak():
+    """tests/test_pitch.py:56-76: a 440 Hz sine peaks at lag sr / 440."""
+    sr = 22050
+    t = np.linspace(0, 0.1, int(sr * 0.1), dtype=np.float32)
+    r = host(ap.autocorrelation(dev(np.sin(2 * np.pi * 440 * t).astype(np.float32)), max_lag=1000))
+    assert r.shape == (1000,)
+    lo, hi = int(sr / 440 * 0.8), int(sr / 440 * 1.2)
+    assert abs(lo + int(np.argmax(r[lo:hi])) - sr / 440) < 5
