@@ -292,6 +292,48 @@ static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, 
     return AP_OK;
 }
 
+// n_fft = 400 wave kernel (kernels_wave400.h: eight frames per wave).  Returns 1 when it does not apply.
+template <class W400>
+static inline int ap_prepare_mel_wave400(W400 &W, const ApStftParams &P, int64_t B, const int32_t *plan,
+                                         const int32_t *desc, int n_waves, int plane_floats, int wmax, int *grid) {
+    if (P.plan.n != 400) return 1;
+    if (!(plan && desc && (desc[0] & AP_PLAN_BANDED) && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
+    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (P.n_mels > 128 || desc[15] > 2) return 1;          // <= 2 parts of <= 16 bins per filter: bands of <= 32 bins
+    if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;      // 32-bit frame and sample arithmetic in the loop
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.fb = P.fb;
+    W.band_lo = P.band_lo;
+    W.band_len = P.band_len;
+    W.out = P.out_mel;
+    W.max_key = nullptr;
+    W.L = P.L;
+    W.T = P.T;
+    W.n_clips = B;
+    W.groups_per_clip = (P.T + 7) / 8;
+    W.n_groups = W.groups_per_clip * B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    W.n_mels = P.n_mels;
+    W.power = P.power;
+    const int m8 = 8 * ((P.n_mels + 7) / 8);
+    int off = 0;
+    W.off_t200 = off; off += 8 * 25 * (int)sizeof(ap_float2);
+    W.off_s400 = off; off += 8 * 25 * (int)sizeof(ap_float2);
+    W.off_w = off; off += m8 * wmax * 4;
+    W.off_lo = off; off += ap_align16((m8 + m8 / 8) * 4);
+    W.off_plane = off; off += n_waves * 8 * plane_floats * 4;
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    int64_t g = (W.n_groups + (int64_t)n_waves * 2 - 1) / ((int64_t)n_waves * 2);    // >= 2 groups per wave
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // n_fft = 1024 wave-per-frame mel kernel (kernels_wave512.h): constant padding, plan with parts,
 // at most 128 filters (two rows per lane).  Returns 1 when it does not apply.
 struct ApMelWave512Params;

@@ -15,6 +15,7 @@
 #include "kernels_ct.h"
 #include "kernels_wave512.h"
 #include "kernels_mel2048.h"
+#include "kernels_wave400.h"
 #include "kernels_features.h"
 
 static thread_local char g_err[512] = "";
@@ -246,6 +247,24 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
             if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
                 return ap_launch_mel_wave_p<0>(W, grid, power, stream);
             return ap_launch_mel_wave_p<1>(W, grid, power, stream);
+        }
+    }
+    if (n_fft == 400) {            // Whisper front end: eight frames per wave (kernels_wave400.h)
+        ApMel400Params W;
+        int grid = 0;
+        static const bool force_ct = std::getenv("AP_MEL400_CT") != nullptr;     // A/B switch: keep the LDS engine
+        if (!force_ct && ap_prepare_mel_wave400(W, P, B, plan, desc, APQ_WAVES, APQ_PS, APQ_WMAX, &grid) == AP_OK) {
+            if (max_key_dev) {
+                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+                if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+                W.max_key = max_key_dev;
+            }
+            auto kern = power == 2.0f ? ap_mel400_wave_kernel<2> : power == 1.0f ? ap_mel400_wave_kernel<1>
+                                                                                  : ap_mel400_wave_kernel<0>;
+            rc = ap_allow_lds(kern, W.lds_bytes);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+            return ap_check_launch("ap_melspec_f32(wave400)");
         }
     }
     if (n_fft == 1024) {

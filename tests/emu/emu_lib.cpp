@@ -14,6 +14,7 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/kernels_ct.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave512.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_mel2048.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_wave400.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -131,6 +132,18 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
             else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 1>(W); });
             else if (!gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 0>(W); });
             else emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 1>(W); });
+            return AP_OK;
+        }
+    }
+    if (n_fft == 400 && !(desc && (desc[0] & 512))) {
+        ApMel400Params W;
+        int grid = 0;
+        if (ap_prepare_mel_wave400(W, P, B, plan, desc, APQ_WAVES, APQ_PS, APQ_WMAX, &grid) == AP_OK) {
+            if (grid > 1) grid = 1;   // exercise the persistent group loop
+            if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
+            if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel400_wave_kernel<2>(W); });
+            else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel400_wave_kernel<1>(W); });
+            else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel400_wave_kernel<0>(W); });
             return AP_OK;
         }
     }

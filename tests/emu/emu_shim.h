@@ -42,6 +42,13 @@ inline float emu_lane_xor(float x, int mask) {
     emu_wave_sync();
     return y;
 }
+inline float emu_lane_perm(float x, int src_lane) {      // value of lane `src_lane` of the same wave
+    emu_xchg[threadIdx.x] = x;
+    emu_wave_sync();
+    const float y = emu_xchg[(threadIdx.x & ~63u) | (unsigned)(src_lane & 63)];
+    emu_wave_sync();
+    return y;
+}
 inline float ap_quad_xor1(float x) { return emu_lane_xor(x, 1); }
 inline float ap_quad_xor2(float x) { return emu_lane_xor(x, 2); }
 

@@ -308,3 +308,25 @@ def test_emu_pcg64_uniform_matches_numpy_bit_for_bit():
         np.testing.assert_array_equal(eb.pcg64_uniform(seed, -np.pi, np.pi, n), want)
     want = np.random.default_rng(3).uniform(0.0, 1.0, 1000).astype(np.float32)
     np.testing.assert_array_equal(eb.pcg64_uniform(3, 0.0, 1.0, 1000), want)
+
+
+@pytest.mark.parametrize("sr,M,hop,L,B,power,center,kw", [
+    (16000, 80, 160, 5000, 3, 2.0, True, {}),          # the Whisper front end
+    (16000, 80, 160, 1300, 2, 1.0, False, {}),         # ragged last group (T = 6), no centring
+    (22050, 128, 100, 3000, 1, 1.5, True, {}),         # 128 filters, another hop and power
+    (16000, 64, 200, 4000, 2, 2.0, True, dict(fmin=300.0, fmax=6000.0, htk=True, norm=None)),
+])
+def test_emu_wave400_kernel(sr, M, hop, L, B, power, center, kw):
+    """kernels_wave400.h (n_fft = 400: eight frames per wave, radix-25 in registers, radix-8 across
+    lanes, band contraction) on the CPU, and the compile-time LDS engine it replaces (tile_kernel)."""
+    rng = np.random.default_rng(M + hop)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 400, 400)
+    fb = ao.mel_filterbank(sr, 400, M, **kw)
+    R = ao.melspectrogram(y, sr=sr, n_fft=400, hop_length=hop, n_mels=M, power=power, center=center, **kw)
+    A, amax = eb.melspec(y, 400, hop, win, fb, power=power, center=center, return_max=True)
+    assert A.shape == R.shape
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()
+    A2 = eb.melspec(y, 400, hop, win, fb, power=power, center=center, tile_kernel=True)
+    np.testing.assert_allclose(A2, R, rtol=1e-4, atol=1e-4)
