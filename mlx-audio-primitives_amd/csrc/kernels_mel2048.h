@@ -58,19 +58,19 @@ AP_DEV ApmLane apm_lane_init(int lane) {
 //   stage 2: out = r - s2 r[lane ^ 1]       (= s2 r' + r'[lane ^ 1] for the unsigned r')
 // outputs in bit-reversed lanes as in apw_forward.
 #ifdef AP_HOST_EMU
-AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
+AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
     for (int i = 0; i < 8; ++i) {
-        x[i] = x[i] + m.c1 * ap_quad_xor2(x[i]);
-        y[i] = y[i] + m.c1 * ap_quad_xor2(y[i]);
+        v[i].x = v[i].x + m.c1 * ap_quad_xor2(v[i].x);
+        v[i].y = v[i].y + m.c1 * ap_quad_xor2(v[i].y);
     }
     for (int i = 0; i < 8; ++i) {
-        const float rx = x[i], ry = y[i];
-        x[i] = m.rot ? ry : rx;
-        y[i] = m.rot ? -rx : ry;
+        const float rx = v[i].x, ry = v[i].y;
+        v[i].x = m.rot ? ry : rx;
+        v[i].y = m.rot ? -rx : ry;
     }
     for (int i = 0; i < 8; ++i) {
-        x[i] = x[i] + m.c2 * ap_quad_xor1(x[i]);
-        y[i] = y[i] + m.c2 * ap_quad_xor1(y[i]);
+        v[i].x = v[i].x + m.c2 * ap_quad_xor1(v[i].x);
+        v[i].y = v[i].y + m.c2 * ap_quad_xor1(v[i].y);
     }
 }
 #else
@@ -78,14 +78,15 @@ AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
 // (d += c * d[lane ^ 2]); the compiler neither folds a DPP move into a VOP2 FMA here nor knows
 // about the DPP read inside an asm, so the block orders its instructions itself: `s_nop 1` covers
 // the 2 wait states between an outside VALU write and the first DPP read of that register, and
-// inside every DPP read sits >= 14 instructions behind the write of its register.
+// inside every DPP read sits >= 14 instructions behind the write of its register.  The halves of
+// the complex register pairs are named directly (v[i].x / v[i].y): no unpacking moves.
 #define APM_S1(i) "v_fmac_f32_dpp %" #i ", %" #i ", %17 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
 #define APM_S2(i) "v_fmac_f32_dpp %" #i ", %" #i ", %18 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 #define APM_ROT(ix, iy)                                  \
     "v_mov_b32 %16, %" #ix "\n\t"                       \
     "v_cndmask_b32 %" #ix ", %" #ix ", %" #iy ", %19\n\t" \
     "v_cndmask_b32 %" #iy ", %" #iy ", -%16, %19\n\t"
-AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
+AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
     float t;
     const unsigned long long rot_mask = 0x8888888888888888ull;      // lane 3 of every quad
     asm volatile(
@@ -96,8 +97,8 @@ AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
         APM_ROT(8, 9) APM_ROT(10, 11) APM_ROT(12, 13) APM_ROT(14, 15)
         APM_S2(0) APM_S2(1) APM_S2(2) APM_S2(3) APM_S2(4) APM_S2(5) APM_S2(6) APM_S2(7)
         APM_S2(8) APM_S2(9) APM_S2(10) APM_S2(11) APM_S2(12) APM_S2(13) APM_S2(14) APM_S2(15)
-        : "+v"(x[0]), "+v"(y[0]), "+v"(x[1]), "+v"(y[1]), "+v"(x[2]), "+v"(y[2]), "+v"(x[3]), "+v"(y[3]),
-          "+v"(x[4]), "+v"(y[4]), "+v"(x[5]), "+v"(y[5]), "+v"(x[6]), "+v"(y[6]), "+v"(x[7]), "+v"(y[7]),
+        : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+          "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y),
           "=&v"(t)
         : "v"(m.c1), "v"(m.c2), "s"(rot_mask));
 }
@@ -107,15 +108,8 @@ AP_DEV void apm_quad8(float (&x)[8], float (&y)[8], const ApmLane &m) {
 #endif
 
 AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
-#pragma unroll
-    for (int h = 0; h < 16; h += 8) {
-        float x[8], y[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { x[i] = v[h + i].x; y[i] = v[h + i].y; }
-        apm_quad8(x, y, m);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[h + i] = ap_mk(x[i], y[i]);
-    }
+    apm_quad8(&v[0], m);
+    apm_quad8(&v[8], m);
 }
 
 // Which frame-invariant per-lane tables stay in REGISTERS for the whole kernel instead of being

@@ -15,7 +15,8 @@
 //   |X|^p -> the wave's 8 power planes in LDS
 //   mel contraction: lane (g, q) owns frame g and the filters m = q + 8 i: a dot product over the
 //   filter's band with zero-padded weights from an LDS table (the 8 lanes of a step hold 8 adjacent
-//   filters, so their band lengths agree to within a few bins); results go straight to HBM.
+//   filters, so their band lengths agree to within a few bins), four steps per trip so that the LDS
+//   reads of 32 filters are in flight together; results go straight to HBM.
 //
 // Per frame ~160 wave-instructions against ~360 (and four workgroup barriers per 8 frames) in the
 // compile-time LDS engine that served this shape before (kernels_ct.h).  Constant padding /
@@ -25,7 +26,7 @@
 
 #define APQ_WAVES 8          // waves per workgroup (they only share read-only LDS tables)
 #define APQ_NC 200           // complex points
-#define APQ_PS 260           // floats per power plane: 201 bins + zero tail for padded band reads, = 4 (mod 32)
+#define APQ_PS 264           // floats per power plane: 201 bins + zero tail for padded band reads, = 8 (mod 32)
 #define APQ_WMAX 32          // floats per filter row of the LDS weight table
 
 struct ApMel400Params {
@@ -106,7 +107,13 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel400_wave_kernel(ApMel
         for (int i = tid; i < 8 * 25; i += nt) {
             const int qq = i / 25, k1 = i - qq * 25;
             const int k2 = 2 * (((qq & 1) << 1) | ((qq >> 1) & 1)) + (qq >> 2);
-            T200[i] = P.tw[(2 * qq * k1) % 400];
+            // W_200^(q k1) times the lane's own factor of the lane ^ 4 stage (sg = s1 s2 of the quad stage):
+            // sg for q < 4 (the lane keeps sg u_q), -sg W_8^(q & 3) for q >= 4 (it keeps -sg W u_q)
+            const int ja = qq & 3;
+            const float sg = (ja == 1 || ja == 2) ? -1.0f : 1.0f;
+            const ap_float2 t = P.tw[(2 * qq * k1) % 400];
+            const ap_float2 f = qq < 4 ? ap_mk(sg, 0.0f) : ap_scale(P.tw[50 * ja], -sg);
+            T200[i] = ap_mk(t.x * f.x - t.y * f.y, t.x * f.y + t.y * f.x);     // product of two forward-form twiddles
             S400[i] = ap_scale(P.tw[k1 + 25 * k2], 0.5f);
         }
         for (int i = tid; i < M8 * APQ_WMAX; i += nt) {
@@ -130,9 +137,12 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel400_wave_kernel(ApMel
 #pragma unroll
     for (int r = 0; r < 25; ++r) win[r] = reinterpret_cast<const ap_float2 *>(P.window)[q + 8 * r];
     const int qa = q & 3;
-    const float s4 = q < 4 ? 1.0f : -1.0f;                    // lane ^ 4 stage: sum (q < 4) or partner - own
-    const ap_float2 w8 = q < 4 ? ap_mk(1.0f, 0.0f) : P.tw[50 * qa];              // W_8^(q & 3) on the difference half
+    // lane ^ 4 stage on the folded values: new = own + partner * kap, kap = W_8^qa for the difference
+    // half (q >= 4: the partner holds sg u), -conj W_8^qa for the sum half (the partner holds -sg W u)
+    const ap_float2 w8 = P.tw[50 * qa];
+    const ap_float2 kap = q < 4 ? ap_mk(-w8.x, w8.y) : w8;
     const float s1 = qa < 2 ? 1.0f : -1.0f, s2 = (qa & 1) ? -1.0f : 1.0f;
+    const float c1 = -s1, c2 = -s2;                            // stage coefficients on values held as (s1 s2) v
     const ap_float2 rotw = qa == 3 ? ap_mk(0.0f, 1.0f) : ap_mk(1.0f, 0.0f);
     const int k2 = 2 * (((q & 1) << 1) | ((q >> 1) & 1)) + (q >> 2);            // block of bins this lane ends up with
     // partner of register 0 (bins 25 k2 <-> 25 (8 - k2)): the lane of this frame whose block is (8 - k2) % 8
@@ -177,35 +187,41 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel400_wave_kernel(ApMel
             {
                 ap_float2 t[25];
 #pragma unroll
-                for (int k1 = 1; k1 < 25; ++k1) t[k1] = T200[q * 25 + k1];
+                for (int k1 = 0; k1 < 25; ++k1) t[k1] = T200[q * 25 + k1];
 #pragma unroll
-                for (int k1 = 1; k1 < 25; ++k1) v[k1] = ap_mul_fw(v[k1], t[k1]);
+                for (int k1 = 0; k1 < 25; ++k1) v[k1] = ap_mul_fw(v[k1], t[k1]);
             }
             // ---- radix-8 across the 8 lanes of the frame ------------------------------------
 #pragma unroll
             for (int k1 = 0; k1 < 25; ++k1) {                 // lane ^ 4: sums / twiddled differences
                 const ap_float2 p = ap_mk(apq_xor4(v[k1].x), apq_xor4(v[k1].y));
-                v[k1] = ap_mul_fw(ap_fma_s(v[k1], s4, p), w8);
+                v[k1] = ap_cmul_tail_fw(p, kap, ap_fma_s(p, kap.x, v[k1]));
             }
+            // quad radix-4: r = h - s1 h[lane ^ 2]; lane 3: r *= -i; out = r - s2 r[lane ^ 1]
+            {
+                // quad radix-4 on DPP moves + packed FMAs, 5 values at a time (values are held as (s1 s2) v).
+                // (The v_fmac_f32_dpp form used by the 2048 kernel measured 15 % slower here: the asm blocks pin
+                // 26 registers each and the allocator spills.)
 #pragma unroll
-            for (int h = 0; h < 25; h += 5) {                  // quad radix-4 (kernels_wave.h), 5 values at a time
-                ap_float2 p[5];
-                AP_SCHED_FENCE();
+                for (int h = 0; h < 25; h += 5) {
+                    ap_float2 p[5];
+                    AP_SCHED_FENCE();
 #pragma unroll
-                for (int i = 0; i < 5; ++i) p[i] = ap_mk(ap_quad_xor2(v[h + i].x), ap_quad_xor2(v[h + i].y));
+                    for (int i = 0; i < 5; ++i) p[i] = ap_mk(ap_quad_xor2(v[h + i].x), ap_quad_xor2(v[h + i].y));
 #pragma unroll
-                for (int i = 0; i < 5; ++i) v[h + i] = ap_fma_s(v[h + i], s1, p[i]);
-                AP_SCHED_FENCE();
+                    for (int i = 0; i < 5; ++i) v[h + i] = ap_fma_s(p[i], c1, v[h + i]);
+                    AP_SCHED_FENCE();
 #pragma unroll
-                for (int i = 0; i < 5; ++i) p[i] = ap_scale(v[h + i], rotw.x);
+                    for (int i = 0; i < 5; ++i) p[i] = ap_scale(v[h + i], rotw.x);
 #pragma unroll
-                for (int i = 0; i < 5; ++i) v[h + i] = ap_cmul_tail_fw(v[h + i], rotw, p[i]);
-                AP_SCHED_FENCE();
+                    for (int i = 0; i < 5; ++i) v[h + i] = ap_cmul_tail_fw(v[h + i], rotw, p[i]);
+                    AP_SCHED_FENCE();
 #pragma unroll
-                for (int i = 0; i < 5; ++i) p[i] = ap_mk(ap_quad_xor1(v[h + i].x), ap_quad_xor1(v[h + i].y));
+                    for (int i = 0; i < 5; ++i) p[i] = ap_mk(ap_quad_xor1(v[h + i].x), ap_quad_xor1(v[h + i].y));
 #pragma unroll
-                for (int i = 0; i < 5; ++i) v[h + i] = ap_fma_s(v[h + i], s2, p[i]);
-                AP_SCHED_FENCE();
+                    for (int i = 0; i < 5; ++i) v[h + i] = ap_fma_s(p[i], c2, v[h + i]);
+                    AP_SCHED_FENCE();
+                }
             }
             // ---- paired real split + power: this lane's bins k = k1 + 25 k2 -----------------
             //   X[k] = (Z[k] + conj Z[200-k]) / 2 + (-i) (W_400^k / 2) (Z[k] - conj Z[200-k])
@@ -233,22 +249,46 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel400_wave_kernel(ApMel
             const int t = t0 + g;
             const float *prow = plane + g * APQ_PS;
             float *ob = P.out + b * (int64_t)M * P.T + t;
-            for (int i = 0; i < NI; ++i) {
-                const int m = 8 * i + q;
-                const int nmax = AP_UNIFORM(LO[M8 + i]);
-                const float *pp = prow + LO[m];
-                const float *wr = WT + m * APQ_WMAX;
-                float acc = 0.0f;
-                for (int j = 0; j < nmax; j += 4) {
-                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(wr + j);
-                    acc = fmaf(w.x, pp[j], acc);
-                    acc = fmaf(w.y, pp[j + 1], acc);
-                    acc = fmaf(w.z, pp[j + 2], acc);
-                    acc = fmaf(w.w, pp[j + 3], acc);
+            // Four steps (32 filters) at a time: one trip of the chunk loop issues 4 weight quads + 16
+            // plane values before it uses any of them, so the wave pays one LDS round trip per 4 bins of
+            // the longest band in the set instead of one per 4 bins of every filter.
+            for (int i0 = 0; i0 < NI; i0 += 4) {
+                const float *pp[4], *wr[4];
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                int nmax = 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int i = i0 + s < NI ? i0 + s : NI - 1;          // a clamped step repeats the last one (not stored)
+                    const int m = 8 * i + q;
+                    const int n = AP_UNIFORM(LO[M8 + i]);
+                    nmax = n > nmax ? n : nmax;
+                    pp[s] = prow + LO[m];
+                    wr[s] = WT + m * APQ_WMAX;
                 }
-                if (m < M && t < Ti) {
-                    ob[(int64_t)m * P.T] = acc;
-                    vmax = fmaxf(vmax, acc);
+                for (int j = 0; j < nmax; j += 4) {
+                    ap_float4 w[4];
+                    float pv[4][4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        w[s] = *reinterpret_cast<const ap_float4 *>(wr[s] + j);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[s][e] = pp[s][j + e];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc[s] = fmaf(w[s].x, pv[s][0], acc[s]);
+                        acc[s] = fmaf(w[s].y, pv[s][1], acc[s]);
+                        acc[s] = fmaf(w[s].z, pv[s][2], acc[s]);
+                        acc[s] = fmaf(w[s].w, pv[s][3], acc[s]);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int m = 8 * (i0 + s) + q;
+                    if (i0 + s < NI && m < M && t < Ti) {
+                        ob[(int64_t)m * P.T] = acc[s];
+                        vmax = fmaxf(vmax, acc[s]);
+                    }
                 }
             }
             AP_WAVE_SYNC();
