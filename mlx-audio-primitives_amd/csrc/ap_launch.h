@@ -41,6 +41,16 @@ static inline int ap_prepare_pad(const float *x, int64_t B, int64_t L, int64_t p
     return AP_OK;
 }
 
+// The bounds-checked sample loads (ApClip in kernels_wave.h) stand in for constant padding.  A lane reads
+// the samples (p, p + 1) with one register offset plus an immediate, and the hardware does not wrap that
+// sum: the pair (-1, 0) would read as (0, 0) and lose sample 0.  Such a pair only exists when centred
+// frames start at odd sample indices (odd hop or odd padding); those shapes take the index-remapping
+// loaders that also serve reflect / edge padding.
+template <class PP>
+static inline bool ap_clip_loads_ok(const PP &P) {
+    return P.pad == 0 || (P.pad_mode == AP_PAD_CONSTANT && !((P.hop | P.pad) & 1));
+}
+
 static inline int ap_prepare_frame(const float *x, int64_t B, int64_t L, int frame_length, int hop,
                                    const float *out, int64_t *T, int *grid) {
     if (!x || !out) AP_FAIL(AP_ERR_INVALID, "frame_signal: NULL buffer");
@@ -239,7 +249,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
 static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, int64_t B, const int32_t *plan,
                                      const int32_t *desc, int n_waves, int x_complex, int partial_off,
                                      int *n_pass, int *grid) {
-    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (!ap_clip_loads_ok(P)) return 1;
     if (P.n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 1;
     if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;          // 32-bit frame and sample arithmetic in the loop
     W.y = P.y;
@@ -292,22 +302,27 @@ static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, 
     return AP_OK;
 }
 
-// n_fft = 400 wave kernel (kernels_wave400.h: eight frames per wave).  Returns 1 when it does not apply.
-template <class W400>
-static inline int ap_prepare_mel_wave400(W400 &W, const ApStftParams &P, int64_t B, const int32_t *plan,
-                                         const int32_t *desc, int n_waves, int plane_floats, int wmax, int *grid) {
-    if (P.plan.n != 400) return 1;
-    if (!(plan && desc && (desc[0] & AP_PLAN_BANDED) && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
-    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
-    if (P.n_mels > 128 || desc[15] > 2) return 1;          // <= 2 parts of <= 16 bins per filter: bands of <= 32 bins
-    if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;      // 32-bit frame and sample arithmetic in the loop
+// Eight-frames-per-wave kernels (kernels_frames8.h): n_fft = 16 R, R in {16, 25, 32}.  The geometry
+// (block stride, plane floats, weight row floats, window in LDS) comes from ApqGeom<R> at the call site.
+// Returns 1 when the kernel does not apply.
+struct ApFrames8Geom { int R, bs, plane_floats, wmax_max, win_lds; };
+template <class W8>
+static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bool mel, const int32_t *plan,
+                                     const int32_t *desc, int n_waves, const ApFrames8Geom &G, int *grid) {
+    if (P.plan.n != 16 * G.R) return 1;
+    if (!ap_clip_loads_ok(P)) return 1;
+    if (P.T > (1 << 19) || P.L > (1 << 28)) return 1;      // 32-bit frame, sample and output-offset arithmetic (a clip's STFT rows < 2 GiB)
+    if (mel) {
+        if (!(plan && desc && (desc[0] & AP_PLAN_BANDED) && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
+        if (P.n_mels > 128 || desc[15] > 4) return 1;      // <= 4 parts of <= 16 bins per filter: bands of <= 64 bins
+    }
     W.y = P.y;
     W.window = P.window;
     W.tw = P.tw;
-    W.fb = P.fb;
-    W.band_lo = P.band_lo;
-    W.band_len = P.band_len;
-    W.out = P.out_mel;
+    W.fb = mel ? P.fb : nullptr;
+    W.band_lo = mel ? P.band_lo : nullptr;
+    W.band_len = mel ? P.band_len : nullptr;
+    W.out = mel ? P.out_mel : reinterpret_cast<float *>(P.out_c);
     W.max_key = nullptr;
     W.L = P.L;
     W.T = P.T;
@@ -316,15 +331,17 @@ static inline int ap_prepare_mel_wave400(W400 &W, const ApStftParams &P, int64_t
     W.n_groups = W.groups_per_clip * B;
     W.hop = P.hop;
     W.pad = P.pad;
-    W.n_mels = P.n_mels;
+    W.n_mels = mel ? P.n_mels : 0;
+    W.wmax = (mel && desc[15] > 2) ? G.wmax_max : G.wmax_max - 32;
     W.power = P.power;
-    const int m8 = 8 * ((P.n_mels + 7) / 8);
+    const int m8 = mel ? 8 * ((P.n_mels + 7) / 8) : 0;
     int off = 0;
-    W.off_t200 = off; off += 8 * 25 * (int)sizeof(ap_float2);
-    W.off_s400 = off; off += 8 * 25 * (int)sizeof(ap_float2);
-    W.off_w = off; off += m8 * wmax * 4;
+    W.off_t = off; off += 8 * G.bs * (int)sizeof(ap_float2);
+    W.off_s = off; off += 8 * G.bs * (int)sizeof(ap_float2);
+    W.off_win = off; off += G.win_lds ? 8 * G.R * (int)sizeof(ap_float2) : 0;
+    W.off_w = off; off += m8 * W.wmax * 4;
     W.off_lo = off; off += ap_align16((m8 + m8 / 8) * 4);
-    W.off_plane = off; off += n_waves * 8 * plane_floats * 4;
+    W.off_plane = off; off += mel ? n_waves * 8 * G.plane_floats * 4 : 0;
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;
     int64_t g = (W.n_groups + (int64_t)n_waves * 2 - 1) / ((int64_t)n_waves * 2);    // >= 2 groups per wave
@@ -342,7 +359,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
                                          const int32_t *desc, int n_waves, int x_complex, int passes_reg,
                                          int *grid) {
     if (!(plan && desc && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
-    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (!ap_clip_loads_ok(P)) return 1;
     if (P.n_mels > 128) return 1;
     W.y = P.y;
     W.window = P.window;
@@ -387,7 +404,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
 template <class W512>
 static inline int ap_prepare_stft_wave512(W512 &W, const ApStftParams &P, int64_t B, int n_waves,
                                           int x_complex, int ob_complex, int *grid) {
-    if (!(P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT)) return 1;
+    if (!ap_clip_loads_ok(P)) return 1;
     if (P.T > (1 << 20)) return 1;                        // 32-bit row offsets in the store phase
     W.y = P.y;
     W.window = P.window;

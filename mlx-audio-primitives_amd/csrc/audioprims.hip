@@ -15,7 +15,7 @@
 #include "kernels_ct.h"
 #include "kernels_wave512.h"
 #include "kernels_mel2048.h"
-#include "kernels_wave400.h"
+#include "kernels_frames8.h"
 #include "kernels_features.h"
 
 static thread_local char g_err[512] = "";
@@ -109,6 +109,47 @@ static int ap_launch_mel_wave_p(const ApMelWaveParams &W, int grid, float power,
     return ap_launch_mel_wave<0, PADGEN>(W, grid, stream);
 }
 
+template <int R>
+static ApFrames8Geom ap_frames8_geom() {
+    ApFrames8Geom G = {R, ApqGeom<R>::BS, ApqGeom<R>::PS, ApqGeom<R>::WMAX, ApqGeom<R>::WIN_REGS ? 0 : 1};
+    return G;
+}
+
+// n_fft = 16 R mel-spectrogram on the eight-frames-per-wave kernel; *handled = false when it does not apply
+template <int R>
+static int ap_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *plan, const int32_t *desc, float power,
+                          uint32_t *max_key_dev, void *stream, bool *handled) {
+    ApFrames8Params W;
+    int grid = 0;
+    *handled = false;
+    if (ap_prepare_frames8(W, P, B, true, plan, desc, APQ_WAVES, ap_frames8_geom<R>(), &grid) != AP_OK) return AP_OK;
+    if (max_key_dev) {
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
+        if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
+        W.max_key = max_key_dev;
+    }
+    auto kern = power == 2.0f ? ap_mel8_wave_kernel<R, 2> : power == 1.0f ? ap_mel8_wave_kernel<R, 1>
+                                                                          : ap_mel8_wave_kernel<R, 0>;
+    int rc = ap_allow_lds(kern, W.lds_bytes);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+    *handled = true;
+    return ap_check_launch("ap_melspec_f32(frames8)");
+}
+
+template <int R>
+static int ap_launch_stft8(const ApStftParams &P, int64_t B, void *stream, bool *handled) {
+    ApFrames8Params W;
+    int grid = 0;
+    *handled = false;
+    if (ap_prepare_frames8(W, P, B, false, nullptr, nullptr, APQ_WAVES, ap_frames8_geom<R>(), &grid) != AP_OK) return AP_OK;
+    int rc = ap_allow_lds(ap_stft8_wave_kernel<R>, W.lds_bytes);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_stft8_wave_kernel<R>, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+    *handled = true;
+    return ap_check_launch("ap_stft_f32(frames8)");
+}
+
 extern "C" {
 
 int ap_version(void) { return 100; }
@@ -166,7 +207,7 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
         ApStftWaveParams W;
         int grid = 0;
         if (ap_prepare_stft_wave(W, P, B, &grid) == AP_OK) {
-            if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT) {
+            if (ap_clip_loads_ok(W)) {
                 rc = ap_allow_lds(ap_stft2048_wave_kernel<0>, W.lds_bytes);
                 if (rc != AP_OK) return rc;
                 hipLaunchKernelGGL(ap_stft2048_wave_kernel<0>, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes,
@@ -191,9 +232,19 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
             return ap_check_launch("ap_stft_f32(wave512)");
         }
     }
+    if (n_fft == 400 || n_fft == 512 || n_fft == 256) {     // eight frames per wave (kernels_frames8.h)
+        static const bool force_ct = std::getenv("AP_STFT8_CT") != nullptr;      // A/B switch: keep the LDS engine
+        if (!force_ct) {
+            bool handled = false;
+            rc = n_fft == 400 ? ap_launch_stft8<25>(P, B, stream, &handled)
+                 : n_fft == 512 ? ap_launch_stft8<32>(P, B, stream, &handled)
+                                : ap_launch_stft8<16>(P, B, stream, &handled);
+            if (rc != AP_OK || handled) return rc;
+        }
+    }
     {
         bool handled = false;
-        rc = (P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? ap_launch_ct<0, 0>(P, n_fft, B, stream, &handled)
+        rc = ap_clip_loads_ok(P) ? ap_launch_ct<0, 0>(P, n_fft, B, stream, &handled)
                                                            : ap_launch_ct<0, 1>(P, n_fft, B, stream, &handled);
         if (rc != AP_OK || handled) return rc;
     }
@@ -244,27 +295,19 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
                 W.max_key = max_key_dev;
             }
             // constant padding (or no centring) needs no index remap: bounds-checked buffer loads
-            if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
+            if (ap_clip_loads_ok(W))
                 return ap_launch_mel_wave_p<0>(W, grid, power, stream);
             return ap_launch_mel_wave_p<1>(W, grid, power, stream);
         }
     }
-    if (n_fft == 400) {            // Whisper front end: eight frames per wave (kernels_wave400.h)
-        ApMel400Params W;
-        int grid = 0;
+    if (n_fft == 400 || n_fft == 512 || n_fft == 256) {     // eight frames per wave (kernels_frames8.h)
         static const bool force_ct = std::getenv("AP_MEL400_CT") != nullptr;     // A/B switch: keep the LDS engine
-        if (!force_ct && ap_prepare_mel_wave400(W, P, B, plan, desc, APQ_WAVES, APQ_PS, APQ_WMAX, &grid) == AP_OK) {
-            if (max_key_dev) {
-                hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
-                if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
-                W.max_key = max_key_dev;
-            }
-            auto kern = power == 2.0f ? ap_mel400_wave_kernel<2> : power == 1.0f ? ap_mel400_wave_kernel<1>
-                                                                                  : ap_mel400_wave_kernel<0>;
-            rc = ap_allow_lds(kern, W.lds_bytes);
-            if (rc != AP_OK) return rc;
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
-            return ap_check_launch("ap_melspec_f32(wave400)");
+        if (!force_ct) {
+            bool handled = false;
+            rc = n_fft == 400 ? ap_launch_mel8<25>(P, B, plan, desc, power, max_key_dev, stream, &handled)
+                 : n_fft == 512 ? ap_launch_mel8<32>(P, B, plan, desc, power, max_key_dev, stream, &handled)
+                                : ap_launch_mel8<16>(P, B, plan, desc, power, max_key_dev, stream, &handled);
+            if (rc != AP_OK || handled) return rc;
         }
     }
     if (n_fft == 1024) {
@@ -286,7 +329,7 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
     }
     if (!(desc && (desc[0] & AP_PLAN_FORCE_GENERIC))) {
         bool handled = false;
-        rc = (P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? ap_launch_ct<1, 0>(P, n_fft, B, stream, &handled)
+        rc = ap_clip_loads_ok(P) ? ap_launch_ct<1, 0>(P, n_fft, B, stream, &handled)
                                                            : ap_launch_ct<1, 1>(P, n_fft, B, stream, &handled);
         if (rc != AP_OK) return rc;
         if (handled) return max_key_dev ? ap_reduce_max_f32(out, B * (int64_t)n_mels * T, max_key_dev, stream) : AP_OK;

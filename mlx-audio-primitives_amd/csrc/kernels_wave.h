@@ -91,6 +91,13 @@ AP_DEV ap_float2 ap_clip16_load2(const ApClip16 &c, int64_t idx) {
     return ap_mk((idx >= 0 && idx < c.n) ? (float)c.base[idx] : 0.0f,
                  (idx + 1 >= 0 && idx + 1 < c.n) ? (float)c.base[idx + 1] : 0.0f);
 }
+// output rows as a bounds-checked buffer: stores outside [0, bytes) are dropped
+struct ApOutBuf { char *base; int64_t bytes; };
+AP_DEV ApOutBuf ap_outbuf_make(void *base, int64_t bytes) { ApOutBuf o; o.base = (char *)base; o.bytes = bytes; return o; }
+AP_DEV void ap_outbuf_store2(const ApOutBuf &o, unsigned lane_bytes, unsigned uniform_bytes, ap_float2 v) {
+    const uint64_t off = (uint64_t)lane_bytes + uniform_bytes;
+    if (lane_bytes < 0x80000000u && off + 8 <= (uint64_t)o.bytes) *reinterpret_cast<ap_float2 *>(o.base + off) = v;
+}
 #else
 #define AP_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)   // tell the compiler x is wave-uniform
 // one clip as a raw buffer resource: the hardware range check returns 0 for every sample
@@ -103,11 +110,23 @@ AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
     // a negative index wraps to a huge unsigned byte offset: out of range -> 0
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c, (int)(idx * 4), 0, 0));
 }
-// samples idx, idx + 1 (idx even or odd: the clip base is 4-byte aligned) as one 8-byte load; the
-// range check is per dword, so a pair that straddles either end of the clip still pads with 0
+// samples idx, idx + 1 as one 8-byte load.  idx must be even or the clip start must not fall inside a
+// pair: the pair (-1, 0) has a wrapped byte offset and reads as (0, 0), losing sample 0 (measured; the
+// launch code only takes this path with even hop and padding).  Past the end the check is per dword.
 AP_DEV ap_float2 ap_clip_load2(ApClip c, int idx) {
     typedef int ap_i2 __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(ap_float2, __builtin_bit_cast(ap_i2, __builtin_amdgcn_raw_buffer_load_b64(c, idx * 4, 0, 0)));
+}
+// output rows as a raw buffer resource (< 4 GiB): the address of a store is base + lane offset (VGPR) +
+// uniform offset (SGPR), so a run of stores to different rows costs no per-store address arithmetic, and
+// a lane parks itself by holding an out-of-range offset (the hardware drops the store)
+typedef __amdgpu_buffer_rsrc_t ApOutBuf;
+AP_DEV ApOutBuf ap_outbuf_make(void *base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+AP_DEV void ap_outbuf_store2(ApOutBuf o, unsigned lane_bytes, unsigned uniform_bytes, ap_float2 v) {
+    typedef int ap_i2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ap_i2, v), o, (int)lane_bytes, (int)uniform_bytes, 0);
 }
 // 16-bit PCM clip (n even, idx even: the launch code guarantees both): one dword = samples idx, idx + 1,
 // converted to float (unscaled: the 1 / 32768 rides on the window); the hardware range check zero-pads

@@ -14,7 +14,7 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/kernels_ct.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave512.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_mel2048.h"
-#include "../../mlx-audio-primitives_amd/csrc/kernels_wave400.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_frames8.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -30,6 +30,32 @@ static bool emu_launch_ct(ApStftParams &P, int n_fft, int64_t B) {
     if (n_fft == 400) emu_launch(grid, 256, [&] { ap_stft_ct_kernel<EPI, 200, 8, 5, 5, 8, PADGEN, 256>(P); });
     else if (n_fft == 512) emu_launch(grid, 256, [&] { ap_stft_ct_kernel<EPI, 256, 16, 16, 1, 8, PADGEN, 256>(P); });
     else emu_launch(grid, 256, [&] { ap_stft_ct_kernel<EPI, 512, 16, 8, 4, 8, PADGEN, 256>(P); });
+    return true;
+}
+
+template <int R>
+static bool emu_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *plan, const int32_t *desc, float power,
+                            unsigned *max_key) {
+    ApFrames8Params W;
+    int grid = 0;
+    const ApFrames8Geom G = {R, ApqGeom<R>::BS, ApqGeom<R>::PS, ApqGeom<R>::WMAX, ApqGeom<R>::WIN_REGS ? 0 : 1};
+    if (ap_prepare_frames8(W, P, B, true, plan, desc, APQ_WAVES, G, &grid) != AP_OK) return false;
+    if (grid > 1) grid = 1;   // exercise the persistent group loop
+    if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
+    if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2>(W); });
+    else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1>(W); });
+    else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0>(W); });
+    return true;
+}
+
+template <int R>
+static bool emu_launch_stft8(const ApStftParams &P, int64_t B) {
+    ApFrames8Params W;
+    int grid = 0;
+    const ApFrames8Geom G = {R, ApqGeom<R>::BS, ApqGeom<R>::PS, ApqGeom<R>::WMAX, ApqGeom<R>::WIN_REGS ? 0 : 1};
+    if (ap_prepare_frames8(W, P, B, false, nullptr, nullptr, APQ_WAVES, G, &grid) != AP_OK) return false;
+    if (grid > 1) grid = 1;
+    emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R>(W); });
     return true;
 }
 
@@ -76,7 +102,7 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
         int grid = 0;
         if (ap_prepare_stft_wave(W, P, B, &grid) == AP_OK) {
             if (grid > 2) grid = 2;   // exercise the persistent group loop
-            if (W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT)
+            if (ap_clip_loads_ok(W))
                 emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<0>(W); });
             else
                 emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<1>(W); });
@@ -92,7 +118,11 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
             return AP_OK;
         }
     }
-    if ((P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? emu_launch_ct<0, 0>(P, n_fft, B) : emu_launch_ct<0, 1>(P, n_fft, B))
+    if (n_fft == 400 || n_fft == 512 || n_fft == 256) {
+        if (n_fft == 400 ? emu_launch_stft8<25>(P, B) : n_fft == 512 ? emu_launch_stft8<32>(P, B) : emu_launch_stft8<16>(P, B))
+            return AP_OK;
+    }
+    if (ap_clip_loads_ok(P) ? emu_launch_ct<0, 0>(P, n_fft, B) : emu_launch_ct<0, 1>(P, n_fft, B))
         return AP_OK;
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
     return AP_OK;
@@ -125,7 +155,7 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
             if (grid > 1) grid = 1;   // exercise the persistent tile loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
-            const bool gen = !(W.pad == 0 || W.pad_mode == AP_PAD_CONSTANT);
+            const bool gen = !ap_clip_loads_ok(W);
             if (power == 2.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 0>(W); });
             else if (power == 2.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 1>(W); });
             else if (power == 1.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 0>(W); });
@@ -135,17 +165,11 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
             return AP_OK;
         }
     }
-    if (n_fft == 400 && !(desc && (desc[0] & 512))) {
-        ApMel400Params W;
-        int grid = 0;
-        if (ap_prepare_mel_wave400(W, P, B, plan, desc, APQ_WAVES, APQ_PS, APQ_WMAX, &grid) == AP_OK) {
-            if (grid > 1) grid = 1;   // exercise the persistent group loop
-            if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
-            if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel400_wave_kernel<2>(W); });
-            else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel400_wave_kernel<1>(W); });
-            else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel400_wave_kernel<0>(W); });
+    if ((n_fft == 400 || n_fft == 512 || n_fft == 256) && !(desc && (desc[0] & 512))) {
+        if (n_fft == 400 ? emu_launch_mel8<25>(P, B, plan, desc, power, max_key)
+            : n_fft == 512 ? emu_launch_mel8<32>(P, B, plan, desc, power, max_key)
+                           : emu_launch_mel8<16>(P, B, plan, desc, power, max_key))
             return AP_OK;
-        }
     }
     if (n_fft == 1024) {
         ApMelWave512Params W;
@@ -160,7 +184,7 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         }
     }
     if (!(desc && (desc[0] & AP_PLAN_FORCE_GENERIC))) {
-        if ((P.pad == 0 || P.pad_mode == AP_PAD_CONSTANT) ? emu_launch_ct<1, 0>(P, n_fft, B) : emu_launch_ct<1, 1>(P, n_fft, B))
+        if (ap_clip_loads_ok(P) ? emu_launch_ct<1, 0>(P, n_fft, B) : emu_launch_ct<1, 1>(P, n_fft, B))
             return AP_OK;
     }
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<1>(P); });

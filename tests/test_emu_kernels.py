@@ -317,7 +317,7 @@ def test_emu_pcg64_uniform_matches_numpy_bit_for_bit():
     (16000, 64, 200, 4000, 2, 2.0, True, dict(fmin=300.0, fmax=6000.0, htk=True, norm=None)),
 ])
 def test_emu_wave400_kernel(sr, M, hop, L, B, power, center, kw):
-    """kernels_wave400.h (n_fft = 400: eight frames per wave, radix-25 in registers, radix-8 across
+    """kernels_frames8.h (n_fft = 400: eight frames per wave, radix-25 in registers, radix-8 across
     lanes, band contraction) on the CPU, and the compile-time LDS engine it replaces (tile_kernel)."""
     rng = np.random.default_rng(M + hop)
     y = rng.standard_normal((B, L)).astype(np.float32)
@@ -330,3 +330,42 @@ def test_emu_wave400_kernel(sr, M, hop, L, B, power, center, kw):
     assert amax == A.max()
     A2 = eb.melspec(y, 400, hop, win, fb, power=power, center=center, tile_kernel=True)
     np.testing.assert_allclose(A2, R, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_fft,sr,M,hop,L,B,power,center,kw", [
+    (512, 22050, 128, 128, 4000, 2, 2.0, True, {}),        # the reference's test grid (test_stft.py:45-46)
+    (512, 22050, 40, 256, 3000, 1, 1.0, False, {}),        # wide top bands (two parts), no centring
+    (512, 16000, 80, 160, 2600, 2, 0.7, True, dict(htk=True)),
+    (256, 8000, 32, 64, 1500, 3, 2.0, True, {}),
+    (256, 16000, 64, 100, 1111, 1, 1.0, True, dict(fmin=100.0, norm=None)),
+])
+def test_emu_frames8_mel_kernels(n_fft, sr, M, hop, L, B, power, center, kw):
+    """The even-R members of kernels_frames8.h (n_fft 512 = 32 x 8 x 2, 256 = 16 x 8 x 2): padded plane
+    blocks, window in LDS for R = 32, band table built in the padded address space."""
+    rng = np.random.default_rng(n_fft + M + hop)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", n_fft, n_fft)
+    fb = ao.mel_filterbank(sr, n_fft, M, **kw)
+    R = ao.melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M, power=power, center=center, **kw)
+    A, amax = eb.melspec(y, n_fft, hop, win, fb, power=power, center=center, return_max=True)
+    assert A.shape == R.shape
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()
+    A2 = eb.melspec(y, n_fft, hop, win, fb, power=power, center=center, tile_kernel=True)   # the engine it replaces
+    np.testing.assert_allclose(A2, R, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_fft,hop,L,B,center", [
+    (512, 128, 4000, 2, True), (512, 256, 2049, 1, True), (512, 512, 3000, 1, False),
+    (400, 160, 3333, 2, True), (400, 77, 1000, 1, False), (256, 64, 1500, 2, True), (256, 33, 700, 1, True),
+])
+def test_emu_frames8_stft_kernels(n_fft, hop, L, B, center):
+    """STFT members of kernels_frames8.h against the oracle (odd hops: sample pairs straddle the clip
+    ends; ragged last groups; hop == n_fft)."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", n_fft, n_fft)
+    want = np.stack([ao.stft(y[b], n_fft=n_fft, hop_length=hop, center=center, pad_mode="constant") for b in range(B)])
+    got = eb.stft(y, n_fft, hop, win, center=center, pad_mode=0)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
