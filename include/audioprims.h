@@ -215,6 +215,29 @@ int ap_resample_poly_f32(const float *x /*dev*/, int64_t B, int64_t L, int up, i
                          const float *taps /*dev*/, int n_taps, int n_pre_remove,
                          int64_t n_out, float *out /*dev*/, void *stream);
 
+/* scipy.signal.resample_poly's other padtypes (the reference forwards `padtype` to SciPy,
+ * resample.py:279-281).  AP_EXT_* are scipy.signal.upfirdn's extension modes; ap_extend_f32 writes
+ * (B, L + 2 n_ext): n_ext extension samples either side of each row (bit-identical to SciPy's
+ * _extend_left / _extend_right).  ap_resample_poly_padded_f32 = extension into `ws`
+ * (B * (L + 2 * ap_resample_poly_pad_samples(up, down, n_taps)) floats) + the polyphase filter; mode
+ * AP_EXT_CONSTANT needs no workspace and is ap_resample_poly_f32.  'mean' / 'median' / 'minimum' /
+ * 'maximum' are host-side: subtract the row statistic, filter with zeros outside, add it back. */
+#define AP_EXT_CONSTANT 0
+#define AP_EXT_WRAP 1
+#define AP_EXT_EDGE 2
+#define AP_EXT_SMOOTH 3
+#define AP_EXT_SYMMETRIC 4
+#define AP_EXT_REFLECT 5
+#define AP_EXT_ANTISYMMETRIC 6
+#define AP_EXT_ANTIREFLECT 7
+#define AP_EXT_LINE 8
+int ap_extend_f32(const float *x /*dev*/, int64_t B, int64_t L, int64_t n_ext, int mode,
+                  float *out /*dev (B, L + 2 n_ext)*/, void *stream);
+int64_t ap_resample_poly_pad_samples(int up, int down, int n_taps);
+int ap_resample_poly_padded_f32(const float *x /*dev*/, int64_t B, int64_t L, int up, int down,
+                                const float *taps /*dev*/, int n_taps, int n_pre_remove, int64_t n_out,
+                                int mode, float *ws /*dev*/, float *out /*dev*/, void *stream);
+
 /* linear-interpolation resampler (resample.py:142-212): positions j*(L-1)/(n_out-1)
  * evaluated in float64 like the reference's NumPy code. */
 int ap_resample_linear_f32(const float *x /*dev*/, int64_t B, int64_t L, int64_t n_out,

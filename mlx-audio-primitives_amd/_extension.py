@@ -50,6 +50,7 @@ ABI_SYMBOLS = [
     "ap_stft_f32", "ap_melspec_f32", "ap_melspec_max_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_workspace_floats",
     "ap_magnitude_f32", "ap_phase_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
+    "ap_extend_f32", "ap_resample_poly_pad_samples", "ap_resample_poly_padded_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
@@ -88,6 +89,9 @@ def _declare(lib) -> None:
         "ap_resample_poly_ntaps": [I, I],
         "ap_resample_poly_taps_host": [I, I, P, P],
         "ap_resample_poly_f32": [P, L, L, I, I, P, I, I, L, P, P],
+        "ap_extend_f32": [P, L, L, L, I, P, P],
+        "ap_resample_poly_pad_samples": [I, I, I],
+        "ap_resample_poly_padded_f32": [P, L, L, I, I, P, I, I, L, I, P, P, P],
         "ap_resample_linear_f32": [P, L, L, L, ctypes.c_double, P, P],
         "ap_gl_project_f32": [I, P, P, P, L, L, L, F, P, P, P],
         "ap_reduce_max_f32": [P, L, P, P],
@@ -121,6 +125,7 @@ def _declare(lib) -> None:
     lib.ap_istft_workspace_floats.restype = L
     lib.ap_autocorrelation_nfft.argtypes = [L]
     lib.ap_autocorrelation_nfft.restype = L
+    lib.ap_resample_poly_pad_samples.restype = L
 
 
 def _load() -> None:

@@ -409,11 +409,12 @@ int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const
     return ap_overlap_add_f32(frames_ws, window, B, T, n_fft, hop, out_offset, out_len, out, stream);
 }
 
-int ap_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
-                         int n_taps, int n_pre_remove, int64_t n_out, float *out, void *stream) {
-    int64_t bpr;
-    int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
-    if (rc != AP_OK) return rc;
+// kept outputs [n_pre_remove, n_pre_remove + n_out) of upfirdn(taps, x, up, down) with zeros outside x
+static int ap_launch_resample_poly(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
+                                   int n_taps, int n_pre_remove, int64_t n_out, float *out, void *stream) {
+    int rc;
+    const int64_t bpr = (n_out + AP_BLOCK - 1) / AP_BLOCK;
+    if (bpr * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "resample_poly: grid too large");
     int lds = 0, Q = 0;
     if (ap_resample_decim_eligible(up, down, n_taps, &Q, &lds)) {
         const int64_t per_block = AP_BLOCK * 4 * Q;
@@ -430,6 +431,50 @@ int ap_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down,
     hipLaunchKernelGGL(ap_resample_poly_kernel, dim3((unsigned)(bpr * B)), dim3(AP_BLOCK), 0,
                        (hipStream_t)stream, x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
     return ap_check_launch("ap_resample_poly_f32");
+}
+
+int ap_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
+                         int n_taps, int n_pre_remove, int64_t n_out, float *out, void *stream) {
+    int64_t bpr;
+    int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
+    if (rc != AP_OK) return rc;
+    return ap_launch_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, stream);
+}
+
+int ap_extend_f32(const float *x, int64_t B, int64_t L, int64_t n_ext, int mode, float *out, void *stream) {
+    if (!x || !out) AP_FAIL(AP_ERR_INVALID, "extend: NULL buffer");
+    if (B <= 0 || L <= 0 || n_ext < 0) AP_FAIL(AP_ERR_INVALID, "extend: signal must be non-empty");
+    if (mode < AP_EXT_CONSTANT || mode > AP_EXT_LINE) AP_FAIL(AP_ERR_INVALID, "extend: unknown mode %d", mode);
+    if (L < 2 && (mode == AP_EXT_SMOOTH || mode == AP_EXT_REFLECT || mode == AP_EXT_ANTIREFLECT || mode == AP_EXT_LINE))
+        AP_FAIL(AP_ERR_INVALID, "extend: this mode needs at least two samples");
+    hipLaunchKernelGGL(ap_extend_kernel, dim3(ap_grid_1d(B * (L + 2 * n_ext), AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, x, B, L, n_ext, mode, out);
+    return ap_check_launch("ap_extend_f32");
+}
+
+int64_t ap_resample_poly_pad_samples(int up, int down, int n_taps) {
+    if (up <= 0 || down <= 0 || n_taps <= 0) return -1;
+    // every kept output reads input samples within n_taps / up of the signal; a multiple of `down` keeps the
+    // output phase: the extended signal's output n + P up / down is the signal's output n
+    const int64_t reach = (n_taps + up - 1) / up + 2;
+    return (reach + down - 1) / down * down;
+}
+
+int ap_resample_poly_padded_f32(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
+                                int n_taps, int n_pre_remove, int64_t n_out, int mode, float *ws, float *out,
+                                void *stream) {
+    int64_t bpr;
+    int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
+    if (rc != AP_OK) return rc;
+    if (mode == AP_EXT_CONSTANT)
+        return ap_launch_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, stream);
+    if (!ws) AP_FAIL(AP_ERR_INVALID, "resample_poly: workspace missing");
+    const int64_t P = ap_resample_poly_pad_samples(up, down, n_taps);
+    rc = ap_extend_f32(x, B, L, P, mode, ws, stream);
+    if (rc != AP_OK) return rc;
+    const int64_t skip = n_pre_remove + P * up / down;
+    if (skip > INT32_MAX) AP_FAIL(AP_ERR_UNSUPPORTED, "resample_poly: ratio too large");
+    return ap_launch_resample_poly(ws, B, L + 2 * P, up, down, taps, n_taps, (int)skip, n_out, out, stream);
 }
 
 int ap_resample_linear_f32(const float *x, int64_t B, int64_t L, int64_t n_out, double scale,

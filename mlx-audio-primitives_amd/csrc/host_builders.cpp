@@ -426,7 +426,7 @@ int ap_resample_poly_taps_host(int up, int down, float *out, int *n_pre_remove_o
     double sum = 0.0;
     for (int n = 0; n < numtaps; ++n) {
         const double m = n - alpha;
-        const double a = kPi * fc * m;
+        const double a = kPi * (fc * m);          // np.sinc(fc * m): pi * x - the rounding of x decides the "zeros"
         const double sinc = (m == 0.0) ? 1.0 : std::sin(a) / a;
         const double r = (n - alpha) / alpha;
         const double arg = 1.0 - r * r;

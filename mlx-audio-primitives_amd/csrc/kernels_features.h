@@ -373,3 +373,100 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_pcm16_to_f32_kernel(const int16_t
     for (int64_t e = 8 * n8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
         out[e] = (float)x[e] * scale;
 }
+
+// Signal extension of scipy.signal.upfirdn (the `mode` of scipy.signal.resample_poly's padtype, which the
+// reference passes through at resample.py:279-281): out (B, L + 2 P) = P extension samples, the signal, P
+// extension samples.  Every branch restates SciPy's _extend_left / _extend_right (third-party:
+// scipy/signal/_upfirdn_apply.pyx, pinned by tests against scipy.signal._upfirdn_apply._pad_test) with the
+// same float32 operation order and no fused multiply-add, so the extension is bit-identical.
+#define AP_EXT_CONSTANT 0
+#define AP_EXT_WRAP 1
+#define AP_EXT_EDGE 2
+#define AP_EXT_SMOOTH 3
+#define AP_EXT_SYMMETRIC 4
+#define AP_EXT_REFLECT 5
+#define AP_EXT_ANTISYMMETRIC 6
+#define AP_EXT_ANTIREFLECT 7
+#define AP_EXT_LINE 8
+
+// One rounding per operation: hipcc's default -ffp-contract=fast would fuse a product into the sum that
+// follows it (and __fmul_rn / __fadd_rn are plain operators under it), so contraction is switched off here.
+#ifdef AP_HOST_EMU
+AP_DEV float ap_mul_rn(float a, float b) { volatile float r = a * b; return r; }
+AP_DEV float ap_add_rn(float a, float b) { volatile float r = a + b; return r; }
+#else
+AP_DEV float ap_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+AP_DEV float ap_add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+#endif
+// float64 quotient rounded once more: exact for float32 operands (53 >= 2 * 24 + 2 bits), whatever the
+// float32 divide expands to
+AP_DEV float ap_div_rn(float a, float b) { return (float)((double)a / (double)b); }
+AP_DEV float ap_sub_rn(float a, float b) { return ap_add_rn(a, -b); }
+
+AP_DEV float ap_extend_sample(const float *x, int64_t L, int64_t i, int mode) {
+    if (i >= 0 && i < L) return x[i];
+    const bool left = i < 0;
+    switch (mode) {
+    case AP_EXT_WRAP: {
+        int64_t j = i % L;
+        if (j < 0) j += L;
+        return x[j];
+    }
+    case AP_EXT_EDGE: return left ? x[0] : x[L - 1];
+    case AP_EXT_SMOOTH:
+        return left ? ap_add_rn(x[0], ap_mul_rn((float)i, ap_sub_rn(x[1], x[0])))
+                    : ap_add_rn(x[L - 1], ap_mul_rn((float)(i - L + 1), ap_sub_rn(x[L - 1], x[L - 2])));
+    case AP_EXT_LINE: {
+        const float slope = ap_div_rn(ap_sub_rn(x[L - 1], x[0]), (float)(L - 1));
+        return left ? ap_add_rn(x[0], ap_mul_rn((float)i, slope))
+                    : ap_add_rn(x[L - 1], ap_mul_rn((float)(i - L + 1), slope));
+    }
+    case AP_EXT_SYMMETRIC:
+    case AP_EXT_ANTISYMMETRIC: {
+        int64_t j = i % (2 * L);
+        if (j < 0) j += 2 * L;
+        if (j < L) return x[j];
+        const float v = x[2 * L - 1 - j];
+        return mode == AP_EXT_ANTISYMMETRIC ? -v : v;
+    }
+    case AP_EXT_REFLECT: {
+        const int64_t per = 2 * (L - 1);
+        int64_t j = i % per;
+        if (j < 0) j += per;
+        return j < L ? x[j] : x[per - j];
+    }
+    case AP_EXT_ANTIREFLECT: {
+        if (left) {
+            if (-i < L) return ap_sub_rn(x[0], ap_sub_rn(x[-i], x[0]));
+            const float le = ap_add_rn(x[0], ap_mul_rn(ap_sub_rn(x[0], x[L - 1]), (float)((-i - 1) / (L - 1))));
+            const int64_t j = (-i - 1) % (2 * (L - 1));
+            if (j < L - 1) return ap_sub_rn(le, ap_sub_rn(x[j + 1], x[0]));
+            return ap_sub_rn(le, ap_sub_rn(x[L - 1], x[L - 2 - (j - (L - 1))]));
+        }
+        if (i < 2 * L - 1) return ap_sub_rn(x[L - 1], ap_sub_rn(x[2 * L - i - 2], x[L - 1]));
+        const float re = ap_add_rn(x[L - 1], ap_mul_rn(ap_sub_rn(x[L - 1], x[0]), (float)(i / (L - 1) - 1)));
+        const int64_t j = i % (2 * (L - 1));
+        if (j < L - 1) return ap_add_rn(re, ap_sub_rn(x[j], x[0]));
+        return ap_add_rn(re, ap_sub_rn(x[L - 1], x[2 * (L - 1) - j]));
+    }
+    default: return 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(AP_BLOCK) ap_extend_kernel(const float *x, int64_t B, int64_t L, int64_t P, int mode,
+                                                            float *out) {
+    const int64_t Lo = L + 2 * P;
+    const int64_t n = B * Lo;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int64_t b = e / Lo;
+        const int64_t i = e - b * Lo - P;
+        out[e] = ap_extend_sample(x + b * L, L, i, mode);
+    }
+}

@@ -58,19 +58,41 @@ def _from_rows(out, lead, axis, ndim):
     return torch.movedim(out, -1, axis) if ndim > 1 else out
 
 
+# scipy.signal.upfirdn's extension modes (AP_EXT_* in include/audioprims.h) and the padtypes SciPy
+# implements by removing a per-row statistic first (scipy.signal.resample_poly: `funcs`)
+_EXT_MODES = {"constant": 0, "wrap": 1, "edge": 2, "smooth": 3, "symmetric": 4, "reflect": 5,
+              "antisymmetric": 6, "antireflect": 7, "line": 8}
+_BACKGROUND = ("mean", "median", "minimum", "maximum")
+
+
+def _row_background(rows: torch.Tensor, padtype: str) -> torch.Tensor:
+    if padtype == "mean":
+        return rows.mean(dim=-1, keepdim=True)
+    if padtype == "minimum":
+        return rows.amin(dim=-1, keepdim=True)
+    if padtype == "maximum":
+        return rows.amax(dim=-1, keepdim=True)
+    srt = torch.sort(rows, dim=-1).values                # np.median: mean of the two middle values
+    n = rows.shape[-1]
+    return ((srt[:, (n - 1) // 2] + srt[:, n // 2]) / 2).unsqueeze(-1)
+
+
 def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constant") -> torch.Tensor:
     """Polyphase resampling by up/down (reference resample.py:215-308 =
-    scipy.signal.resample_poly(y, up, down, axis, padtype='constant'))."""
+    scipy.signal.resample_poly(y, up, down, axis, padtype=padtype)).
+
+    padtype: 'constant' (default), upfirdn's extension modes 'line', 'symmetric', 'reflect', 'edge',
+    'wrap', 'smooth', 'antisymmetric', 'antireflect' (the signal is extended on the device and filtered
+    by the same kernel), or 'mean' / 'median' / 'minimum' / 'maximum' (the row statistic is removed,
+    the rest filtered against zeros, the statistic added back - as SciPy does)."""
     validate_positive(up, "up")
     validate_positive(down, "down")
     g = math.gcd(int(up), int(down))
     up, down = int(up) // g, int(down) // g
     if up == 1 and down == 1:
         return y                                         # resample.py:259
-    if padtype != "constant":
-        raise ValueError(
-            f"padtype='{padtype}' is not available on the HIP path (only 'constant', "
-            "the reference's default)")
+    if padtype not in _EXT_MODES and padtype not in _BACKGROUND:
+        raise ValueError(f"padtype must be one of {sorted(_BACKGROUND) + sorted(_EXT_MODES)}, got '{padtype}'")
     ndim = y.ndim if hasattr(y, "ndim") else np.ndim(y)
     rows, lead = _as_rows(y, axis)
     R, L = rows.shape
@@ -78,9 +100,25 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
     out = torch.empty((R, n_out), dtype=torch.float32, device=rows.device)
     if R > 0 and L > 0:
         taps, n_pre_remove = _poly_taps(up, down, rows.device)
-        _x.check(_x.dlib(rows.device).ap_resample_poly_f32(_x.ptr(rows), R, L, up, down, _x.ptr(taps),
-                                               taps.numel(), n_pre_remove, n_out, _x.ptr(out),
-                                               _x.stream_ptr(rows.device)))
+        background = None
+        if padtype in _BACKGROUND:
+            background = _row_background(rows, padtype)
+            rows = rows - background
+        mode = _EXT_MODES.get(padtype, 0)
+        if mode == 0:
+            _x.check(_x.dlib(rows.device).ap_resample_poly_f32(_x.ptr(rows), R, L, up, down, _x.ptr(taps),
+                                                   taps.numel(), n_pre_remove, n_out, _x.ptr(out),
+                                                   _x.stream_ptr(rows.device)))
+        else:
+            if L < 2 and padtype in ("smooth", "reflect", "antireflect", "line"):
+                raise ValueError(f"padtype='{padtype}' needs at least two samples")
+            n_ext = int(_x.lib().ap_resample_poly_pad_samples(up, down, taps.numel()))
+            ws = torch.empty((R, L + 2 * n_ext), dtype=torch.float32, device=rows.device)
+            _x.check(_x.dlib(rows.device).ap_resample_poly_padded_f32(
+                _x.ptr(rows), R, L, up, down, _x.ptr(taps), taps.numel(), n_pre_remove, n_out, mode,
+                _x.ptr(ws), _x.ptr(out), _x.stream_ptr(rows.device)))
+        if background is not None:
+            out += background
     return _from_rows(out, lead, axis, ndim)
 
 

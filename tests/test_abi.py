@@ -147,3 +147,21 @@ def test_cpu_baseline_variant_matches_oracle():
     a = ao.melspectrogram_cpu_baseline(y[None], workers=2)
     b = ao.melspectrogram(y[None])
     np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_host_resample_poly_taps_are_scipys_bit_for_bit():
+    """ap_resample_poly_taps_host == the float32 filter scipy.signal.resample_poly builds (firwin + Kaiser
+    5.0, cast, * up, leading zeros) in every bit - including the 1e-17-sized values numpy's sinc leaves
+    at the filter's zero crossings, which decide the last bits of outputs that nearly cancel."""
+    from scipy.signal import firwin
+    from mlx_audio_primitives_amd.resample import _poly_taps_host
+    for up, down in ((3, 2), (1, 3), (160, 147), (2, 1), (1, 2), (1, 8), (5, 7), (147, 160), (7, 1), (1, 5)):
+        raw, n_pre_remove = _poly_taps_host(up, down)
+        taps = np.frombuffer(raw, dtype=np.float32)
+        max_rate = max(up, down)
+        half_len = 10 * max_rate
+        h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)).astype(np.float32)
+        h *= np.float32(up)
+        n_pre_pad = down - half_len % down
+        np.testing.assert_array_equal(taps, np.concatenate([np.zeros(n_pre_pad, np.float32), h]))
+        assert n_pre_remove == (half_len + n_pre_pad) // down

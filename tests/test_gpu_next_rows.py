@@ -149,3 +149,68 @@ def test_autocorrelation_sine_peak():
     assert r.shape == (1000,)
     lo, hi = int(sr / 440 * 0.8), int(sr / 440 * 1.2)
     assert abs(lo + int(np.argmax(r[lo:hi])) - sr / 440) < 5
+
+
+# ------------------------------------------------------------------ resample_poly padtypes
+_EXT = ["line", "symmetric", "reflect", "edge", "wrap", "smooth", "antisymmetric", "antireflect"]
+
+
+@pytest.mark.parametrize("mode", ["constant"] + _EXT)
+def test_extend_matches_scipy_bit_for_bit(mode):
+    """ap_extend_f32 against scipy.signal.upfirdn's own extension (its _pad_test hook) and the oracle."""
+    import ctypes
+    from scipy.signal._upfirdn_apply import _pad_test
+    from mlx_audio_primitives_amd import _extension as ext
+    from mlx_audio_primitives_amd.resample import _EXT_MODES
+    rng = np.random.default_rng(11)
+    for B, L, n_ext in ((3, 1000, 70), (2, 5, 19), (1, 2, 7), (4, 333, 333)):
+        x = (rng.standard_normal((B, L)) + 0.3).astype(np.float32)
+        xd = dev(x)
+        out = torch.empty((B, L + 2 * n_ext), dtype=torch.float32, device="cuda")
+        ext.check(ext.dlib(xd.device).ap_extend_f32(ext.ptr(xd), B, L, n_ext, _EXT_MODES[mode], ext.ptr(out),
+                                                    ext.stream_ptr(xd.device)))
+        got = host(out)
+        for b in range(B):
+            np.testing.assert_array_equal(got[b], _pad_test(x[b], npre=n_ext, npost=n_ext, mode=mode))
+            np.testing.assert_array_equal(got[b], ao.upfirdn_extend(x[b], n_ext, mode))
+
+
+@pytest.mark.parametrize("padtype", _EXT)
+@pytest.mark.parametrize("up,down", [(1, 3), (2, 1), (3, 2), (160, 147), (1, 8)])
+def test_resample_poly_extension_padtypes_bit_exact(padtype, up, down):
+    """Reference resample.py:279-281 forwards padtype to scipy.signal.resample_poly: same float32 taps,
+    same extension samples, same accumulation order -> identical bits."""
+    import scipy.signal
+    rng = np.random.default_rng(up * 100 + down)
+    x = (rng.standard_normal((3, 4001)) + 0.5).astype(np.float32)
+    want = scipy.signal.resample_poly(x, up, down, axis=-1, padtype=padtype).astype(np.float32)
+    got = host(ap.resample_poly(dev(x), up, down, padtype=padtype))
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(ao.resample_poly(x, up, down, padtype=padtype), want)
+
+
+@pytest.mark.parametrize("padtype", ["mean", "median", "minimum", "maximum"])
+def test_resample_poly_background_padtypes(padtype):
+    import scipy.signal
+    rng = np.random.default_rng(5)
+    for L in (4000, 4001):
+        x = (rng.standard_normal((4, L)) + 3.0).astype(np.float32)
+        want = scipy.signal.resample_poly(x, 1, 3, axis=-1, padtype=padtype).astype(np.float32)
+        got = host(ap.resample_poly(dev(x), 1, 3, padtype=padtype))
+        if padtype == "mean":            # the row mean is summed in another order than np.mean's pairwise sum
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=2e-6)
+        else:
+            np.testing.assert_array_equal(got, want)
+
+
+def test_resample_poly_padtype_errors_and_short_signals():
+    import scipy.signal
+    x = np.arange(12, dtype=np.float32).reshape(2, 6)
+    with pytest.raises(ValueError, match="padtype must be one of"):
+        ap.resample_poly(dev(x), 1, 2, padtype="nearest")
+    with pytest.raises(ValueError, match="at least two samples"):
+        ap.resample_poly(dev(x[:, :1]), 1, 2, padtype="line")
+    for padtype in _EXT:                  # the extension is many signal lengths deep
+        want = scipy.signal.resample_poly(x, 3, 2, axis=-1, padtype=padtype).astype(np.float32)
+        np.testing.assert_array_equal(host(ap.resample_poly(dev(x), 3, 2, padtype=padtype)), want)

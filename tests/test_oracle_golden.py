@@ -181,3 +181,18 @@ def test_oracle_feature_properties_and_scipy_identities():
                                rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError, match="width must be odd"):
         ao.delta(M, width=4)
+
+
+@pytest.mark.parametrize("mode", ["constant", "wrap", "edge", "smooth", "symmetric", "reflect", "antisymmetric",
+                                  "antireflect", "line"])
+def test_upfirdn_extend_pinned_to_scipy(mode):
+    """oracle.upfirdn_extend == SciPy's own _extend_left / _extend_right (through its _pad_test hook), bit
+    for bit, including extensions several signal lengths deep."""
+    from scipy.signal._upfirdn_apply import _pad_test
+    rng = np.random.default_rng(3)
+    for L in (2, 3, 5, 17, 100):
+        x = rng.standard_normal(L).astype(np.float32)
+        for n_ext in (1, 4, L - 1, L, 3 * L + 2):
+            if n_ext > 0:
+                np.testing.assert_array_equal(ao.upfirdn_extend(x, n_ext, mode),
+                                              _pad_test(x, npre=n_ext, npost=n_ext, mode=mode))
