@@ -256,6 +256,19 @@ int ap_resample_fft_f32(const float *x /*dev (B,Nx)*/, int64_t B, int64_t Nx, in
                         const float *tw_y2 /*dev*/, float *ws /*dev*/, float *out /*dev (B,num)*/,
                         void *stream);
 
+/* The same for lengths with a prime factor > 4096: either transform may run as a chirp-z (Bluestein)
+ * convolution of a supported length M >= 2 N - 1 (a power of two).  Mx / My = 0 keeps the direct
+ * four-step transform for that side (tw_*: legs of N); Mx / My > 0: tw_* are the leg tables of M,
+ * chirp_* (N complex64) = exp(-i pi n^2 / N), spec_* (M complex64) = FFT_M of conj(chirp) laid out
+ * circularly (b[n] = b[M - n] = conj(chirp[n])), both built on the host in float64.
+ *   ws : 2 * B * max(Nx, num, Mx, My) complex64. */
+int ap_resample_fft_chirp_f32(const float *x /*dev (B,Nx)*/, int64_t B, int64_t Nx, int64_t num,
+                              int64_t Mx, const float *tw_x1, const float *tw_x2,
+                              const float *chirp_x, const float *spec_x,
+                              int64_t My, const float *tw_y1, const float *tw_y2,
+                              const float *chirp_y, const float *spec_y /*dev*/,
+                              float *ws /*dev*/, float *out /*dev (B,num)*/, void *stream);
+
 /* magnitude / phase / |S|^p of a complex64 array of n elements —
  * stft.py:347-379 (mx.abs, mx.arctan2). */
 int ap_magnitude_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "ap_stft_f32", "ap_melspec_f32", "ap_melspec_max_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_workspace_floats",
     "ap_magnitude_f32", "ap_phase_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
-    "ap_extend_f32", "ap_resample_poly_pad_samples", "ap_resample_poly_padded_f32",
+    "ap_extend_f32", "ap_resample_poly_pad_samples", "ap_resample_poly_padded_f32", "ap_resample_fft_chirp_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
@@ -104,6 +104,7 @@ def _declare(lib) -> None:
                                  ctypes.c_double, ctypes.c_double, L, P, P],
         "ap_griffinlim_f32": [P, P, L, L, I, I, P, P, I, I, L, L, L, I, F, P, P, P, P, P, P],
         "ap_resample_fft_f32": [P, L, L, L, P, P, P, P, P, P, P],
+        "ap_resample_fft_chirp_f32": [P, L, L, L, L, P, P, P, P, L, P, P, P, P, P, P, P],
         "ap_phase_f32": [P, L, P, P],
         "ap_spectral_stats_f32": [P, I, L, L, L, P, F, P, F, I, F, F, P, P, P, P, P],
         "ap_frame_stats_f32": [P, L, L, I, I, I, I, L, P, P, P],

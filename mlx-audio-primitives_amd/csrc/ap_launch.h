@@ -565,6 +565,83 @@ static inline int ap_prepare_cfft(ApCfftParams &L1, ApCfftParams &L2, const void
     return AP_OK;
 }
 
+// One side (forward or inverse) of the FFT resampler: a length-N transform either directly on the
+// four-step engine (M == 0: tw1 / tw2 are the leg tables of N) or as a chirp-z convolution of length M
+// (tw1 / tw2: leg tables of M; chirp: N complex; spec: M complex).
+struct ApCfftSide {
+    int64_t N, M;
+    const float *tw1, *tw2, *chirp, *spec;
+};
+
+// scipy.signal.resample for real rows = forward transform, spectrum surgery, inverse transform.  `Ops`
+// launches the kernels (HIP in audioprims.hip, the CPU emulator in tests/emu): leg(ApCfftParams, B),
+// spectrum(X, Nx, Y, num, B), chirp_pre(in, real_in, N, chirp, conj, out, M, B),
+// chirp_spec(buf, spec, conj, M, B), chirp_post(buf, M, chirp, conj, N, scale, real_out, out, B).
+// ws: two complex buffers of B * max(Nx, num, Mx, My) elements.
+template <class Ops>
+static inline int ap_cfft_inplace(Ops &ops, ap_float2 *buf, ap_float2 *mid, int64_t B, int64_t M, const float *tw1,
+                                  const float *tw2, int inverse, float scale) {
+    int m1, m2;
+    if (ap_cfft_split(M, &m1, &m2) != 0) AP_FAIL(AP_ERR_UNSUPPORTED, "cfft: length %lld cannot be factored", (long long)M);
+    ApCfftParams L1, L2;
+    int rc = ap_prepare_cfft(L1, L2, buf, mid, buf, B, M, m1, m2, tw1, tw2, inverse, 0, 0, scale);
+    if (rc != AP_OK) return rc;
+    rc = ops.leg(L1, B);
+    if (rc != AP_OK) return rc;
+    return ops.leg(L2, B);
+}
+
+template <class Ops>
+static inline int ap_resample_fft_compose(Ops &ops, const float *x, int64_t B, const ApCfftSide &X, const ApCfftSide &Y,
+                                          float *ws, float *out) {
+    const int64_t Nx = X.N, num = Y.N;
+    int64_t Nmax = Nx > num ? Nx : num;
+    if (X.M > Nmax) Nmax = X.M;
+    if (Y.M > Nmax) Nmax = Y.M;
+    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ws);
+    ap_float2 *bufB = bufA + B * Nmax;
+    ApCfftParams L1, L2;
+    int rc;
+    // ---- forward: x (real) -> bufB = X (B, Nx)
+    if (X.M == 0) {
+        int a1, a2;
+        if (ap_cfft_split(Nx, &a1, &a2) != 0)
+            AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): length %lld has no factorisation N1*N2 with both <= %d",
+                    (long long)Nx, AP_CFFT_MAX);
+        rc = ap_prepare_cfft(L1, L2, x, bufA, bufB, B, Nx, a1, a2, X.tw1, X.tw2, 0, 1, 0, 1.0f);
+        if (rc != AP_OK) return rc;
+        if ((rc = ops.leg(L1, B)) != AP_OK) return rc;
+        if ((rc = ops.leg(L2, B)) != AP_OK) return rc;
+    } else {
+        if (X.M < 2 * Nx - 1) AP_FAIL(AP_ERR_INVALID, "resample(fft): chirp length %lld < 2 N - 1", (long long)X.M);
+        if ((rc = ops.chirp_pre(x, 1, Nx, X.chirp, 0, bufA, X.M, B)) != AP_OK) return rc;
+        if ((rc = ap_cfft_inplace(ops, bufA, bufB, B, X.M, X.tw1, X.tw2, 0, 1.0f)) != AP_OK) return rc;
+        if ((rc = ops.chirp_spec(bufA, X.spec, 0, X.M, B)) != AP_OK) return rc;
+        if ((rc = ap_cfft_inplace(ops, bufA, bufB, B, X.M, X.tw1, X.tw2, 1, (float)(1.0 / (double)X.M))) != AP_OK) return rc;
+        if ((rc = ops.chirp_post(bufA, X.M, X.chirp, 0, Nx, 1.0f, 0, bufB, B)) != AP_OK) return rc;
+    }
+    // ---- spectrum surgery: bufB (B, Nx) -> bufA (B, num), the full Hermitian spectrum
+    if ((rc = ops.spectrum(bufB, Nx, bufA, num, B)) != AP_OK) return rc;
+    // ---- inverse: bufA -> out (real), scale = (1 / num) * (num / Nx) = 1 / Nx
+    const float scale = (float)(1.0 / (double)Nx);
+    if (Y.M == 0) {
+        int b1, b2;
+        if (ap_cfft_split(num, &b1, &b2) != 0)
+            AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): length %lld has no factorisation N1*N2 with both <= %d",
+                    (long long)num, AP_CFFT_MAX);
+        rc = ap_prepare_cfft(L1, L2, bufA, bufB, out, B, num, b1, b2, Y.tw1, Y.tw2, 1, 0, 1, scale);
+        if (rc != AP_OK) return rc;
+        if ((rc = ops.leg(L1, B)) != AP_OK) return rc;
+        return ops.leg(L2, B);
+    }
+    if (Y.M < 2 * num - 1) AP_FAIL(AP_ERR_INVALID, "resample(fft): chirp length %lld < 2 N - 1", (long long)Y.M);
+    if ((rc = ops.chirp_pre(bufA, 0, num, Y.chirp, 1, bufB, Y.M, B)) != AP_OK) return rc;
+    if ((rc = ap_cfft_inplace(ops, bufB, bufA, B, Y.M, Y.tw1, Y.tw2, 0, 1.0f)) != AP_OK) return rc;
+    if ((rc = ops.chirp_spec(bufB, Y.spec, 1, Y.M, B)) != AP_OK) return rc;
+    if ((rc = ap_cfft_inplace(ops, bufB, bufA, B, Y.M, Y.tw1, Y.tw2, 1, (float)(1.0 / (double)Y.M))) != AP_OK) return rc;
+    return ops.chirp_post(bufB, Y.M, Y.chirp, 1, num, scale, 1, out, B);
+}
+
 static inline int ap_prepare_irfft_wave(ApIrfftWaveParams &W, const ApIrfftParams &P, int64_t B, int *grid) {
     W.S = P.S;
     W.tw = P.tw;

@@ -672,43 +672,56 @@ int ap_cfft_split_host(int64_t N, int *N1, int *N2) {
     return ap_cfft_split(N, N1, N2) == 0 ? AP_OK : AP_ERR_UNSUPPORTED;
 }
 
+namespace {
+struct ApHipFftOps {                      // kernel launches of ap_resample_fft_compose on a HIP stream
+    void *stream;
+    int leg(const ApCfftParams &C, int64_t B) { return ap_launch_cfft_leg(C, B, stream); }
+    int spectrum(const ap_float2 *X, int64_t Nx, ap_float2 *Y, int64_t num, int64_t B) {
+        hipLaunchKernelGGL(ap_resample_spectrum_kernel, dim3(ap_grid_1d(B * num, AP_BLOCK, kApStreamGrid)),
+                           dim3(AP_BLOCK), 0, (hipStream_t)stream, X, Nx, Y, num, B);
+        return ap_check_launch("ap_resample_spectrum");
+    }
+    int chirp_pre(const void *in, int real_in, int64_t N, const float *chirp, int conj, ap_float2 *out, int64_t M,
+                  int64_t B) {
+        hipLaunchKernelGGL(ap_chirp_pre_kernel, dim3(ap_grid_1d(B * M, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                           (hipStream_t)stream, in, real_in, N, reinterpret_cast<const ap_float2 *>(chirp), conj, out, M, B);
+        return ap_check_launch("ap_chirp_pre");
+    }
+    int chirp_spec(ap_float2 *buf, const float *spec, int conj, int64_t M, int64_t B) {
+        hipLaunchKernelGGL(ap_chirp_spec_kernel, dim3(ap_grid_1d(B * M, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                           (hipStream_t)stream, buf, reinterpret_cast<const ap_float2 *>(spec), conj, M, B);
+        return ap_check_launch("ap_chirp_spec");
+    }
+    int chirp_post(const ap_float2 *buf, int64_t M, const float *chirp, int conj, int64_t N, float scale, int real_out,
+                   void *out, int64_t B) {
+        hipLaunchKernelGGL(ap_chirp_post_kernel, dim3(ap_grid_1d(B * N, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                           (hipStream_t)stream, buf, M, reinterpret_cast<const ap_float2 *>(chirp), conj, N, scale,
+                           real_out, out, B);
+        return ap_check_launch("ap_chirp_post");
+    }
+};
+}  // namespace
+
 int ap_resample_fft_f32(const float *x, int64_t B, int64_t Nx, int64_t num, const float *tw_x1,
                         const float *tw_x2, const float *tw_y1, const float *tw_y2, float *ws,
                         float *out, void *stream) {
+    return ap_resample_fft_chirp_f32(x, B, Nx, num, 0, tw_x1, tw_x2, nullptr, nullptr, 0, tw_y1, tw_y2, nullptr,
+                                     nullptr, ws, out, stream);
+}
+
+int ap_resample_fft_chirp_f32(const float *x, int64_t B, int64_t Nx, int64_t num, int64_t Mx, const float *tw_x1,
+                              const float *tw_x2, const float *chirp_x, const float *spec_x, int64_t My,
+                              const float *tw_y1, const float *tw_y2, const float *chirp_y, const float *spec_y,
+                              float *ws, float *out, void *stream) {
     if (!x || !out || !ws || !tw_x1 || !tw_x2 || !tw_y1 || !tw_y2)
         AP_FAIL(AP_ERR_INVALID, "resample(fft): NULL buffer");
     if (B <= 0 || Nx <= 0 || num <= 0) AP_FAIL(AP_ERR_INVALID, "resample(fft): empty signal");
-    int a1, a2, b1, b2;
-    if (ap_cfft_split(Nx, &a1, &a2) != 0)
-        AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): length %lld has no factorisation N1*N2 with both <= %d",
-                (long long)Nx, AP_CFFT_MAX);
-    if (ap_cfft_split(num, &b1, &b2) != 0)
-        AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): length %lld has no factorisation N1*N2 with both <= %d",
-                (long long)num, AP_CFFT_MAX);
-    const int64_t Nmax = Nx > num ? Nx : num;
-    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ws);
-    ap_float2 *bufB = bufA + B * Nmax;
-    ApCfftParams L1, L2;
-    // forward: x (real) -> bufA (leg scratch) -> bufB = X (B, Nx)
-    int rc = ap_prepare_cfft(L1, L2, x, bufA, bufB, B, Nx, a1, a2, tw_x1, tw_x2, 0, 1, 0, 1.0f);
-    if (rc != AP_OK) return rc;
-    L2.out_batch = Nx;
-    rc = ap_launch_cfft_leg(L1, B, stream);
-    if (rc != AP_OK) return rc;
-    rc = ap_launch_cfft_leg(L2, B, stream);
-    if (rc != AP_OK) return rc;
-    // spectrum surgery: bufB (B, Nx) -> bufA (B, num) full Hermitian
-    hipLaunchKernelGGL(ap_resample_spectrum_kernel, dim3(ap_grid_1d(B * num, AP_BLOCK, kApStreamGrid)),
-                       dim3(AP_BLOCK), 0, (hipStream_t)stream, bufB, Nx, bufA, num, B);
-    rc = ap_check_launch("ap_resample_spectrum");
-    if (rc != AP_OK) return rc;
-    // inverse: bufA -> bufB (leg scratch) -> out (real), scale = (1/num) * (num/Nx) = 1/Nx
-    rc = ap_prepare_cfft(L1, L2, bufA, bufB, out, B, num, b1, b2, tw_y1, tw_y2, 1, 0, 1,
-                         (float)(1.0 / (double)Nx));
-    if (rc != AP_OK) return rc;
-    rc = ap_launch_cfft_leg(L1, B, stream);
-    if (rc != AP_OK) return rc;
-    return ap_launch_cfft_leg(L2, B, stream);
+    if ((Mx > 0 && (!chirp_x || !spec_x)) || (My > 0 && (!chirp_y || !spec_y)) || Mx < 0 || My < 0)
+        AP_FAIL(AP_ERR_INVALID, "resample(fft): chirp tables missing");
+    const ApCfftSide X = {Nx, Mx, tw_x1, tw_x2, chirp_x, spec_x};
+    const ApCfftSide Y = {num, My, tw_y1, tw_y2, chirp_y, spec_y};
+    ApHipFftOps ops = {stream};
+    return ap_resample_fft_compose(ops, x, B, X, Y, ws, out);
 }
 
 static int ap_complex_unary(const float *S, int64_t n, int mode, float *out, void *stream) {

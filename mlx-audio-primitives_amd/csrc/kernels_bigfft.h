@@ -100,3 +100,56 @@ ap_resample_spectrum_kernel(const ap_float2 *X, int64_t Nx, ap_float2 *Y, int64_
         Y[e] = v;
     }
 }
+
+// ---- chirp-z (Bluestein) wrapping of the four-step transform ------------------------------------
+// A length-N DFT for N with a prime factor the LDS legs cannot hold, as a circular convolution of a
+// supported length M >= 2N - 1:  n k = (n^2 + k^2 - (k - n)^2) / 2, so with c[n] = exp(-i pi n^2 / N)
+//   X[k] = c[k] * sum_n (x[n] c[n]) * conj(c)[k - n]
+// pre:  a[n] = x[n] c[n] (n < N), 0 up to M;  then A = FFT_M(a), A *= FFT_M(conj c, wrapped) (a host-built
+// table), a' = IFFT_M(A);  post: X[k] = c[k] a'[k].  The inverse transform conjugates all three factors.
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_chirp_pre_kernel(const void *in, int real_in, int64_t N, const ap_float2 *chirp, int conj, ap_float2 *out,
+                    int64_t M, int64_t B) {
+    const int64_t total = B * M;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / M, n = e - b * M;
+        ap_float2 v = ap_mk(0.0f, 0.0f);
+        if (n < N) {
+            const ap_float2 x = real_in ? ap_mk(reinterpret_cast<const float *>(in)[b * N + n], 0.0f)
+                                        : reinterpret_cast<const ap_float2 *>(in)[b * N + n];
+            ap_float2 c = chirp[n];
+            if (conj) c.y = -c.y;
+            v = ap_mk(x.x * c.x - x.y * c.y, x.x * c.y + x.y * c.x);
+        }
+        out[e] = v;
+    }
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_chirp_spec_kernel(ap_float2 *buf, const ap_float2 *spec, int conj, int64_t M, int64_t B) {
+    const int64_t total = B * M;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const ap_float2 x = buf[e];
+        ap_float2 c = spec[e % M];
+        if (conj) c.y = -c.y;
+        buf[e] = ap_mk(x.x * c.x - x.y * c.y, x.x * c.y + x.y * c.x);
+    }
+}
+
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_chirp_post_kernel(const ap_float2 *buf, int64_t M, const ap_float2 *chirp, int conj, int64_t N, float scale,
+                     int real_out, void *out, int64_t B) {
+    const int64_t total = B * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t b = e / N, k = e - b * N;
+        const ap_float2 x = buf[b * M + k];
+        ap_float2 c = chirp[k];
+        if (conj) c.y = -c.y;
+        const ap_float2 v = ap_mk((x.x * c.x - x.y * c.y) * scale, (x.x * c.y + x.y * c.x) * scale);
+        if (real_out) reinterpret_cast<float *>(out)[e] = v.x;
+        else reinterpret_cast<ap_float2 *>(out)[e] = v;
+    }
+}

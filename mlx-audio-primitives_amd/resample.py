@@ -6,7 +6,7 @@ that reproduces scipy.signal.resample_poly for float32 input (same taps, same
 accumulation order), ``res_type='linear'`` is a float64-position interpolation kernel and
 ``res_type='fft'`` (scipy.signal.resample: one whole-clip FFT of arbitrary length) is a
 four-step large-N FFT whose two legs both run in LDS (lengths N = N1*N2 with N1, N2 <= 4096;
-anything else raises instead of silently running on the CPU).
+any other length goes through the same engine as a chirp-z / Bluestein convolution).
 """
 
 from __future__ import annotations
@@ -123,30 +123,63 @@ def resample_poly(y, up: int, down: int, axis: int = -1, padtype: str = "constan
 
 
 def _cfft_split(n: int):
+    """N = N1 * N2 with both legs LDS-resident (<= 4096), or None."""
     import ctypes
     a, b = ctypes.c_int(0), ctypes.c_int(0)
     rc = _x.lib().ap_cfft_split_host(int(n), ctypes.addressof(a), ctypes.addressof(b))
-    if rc != 0:
-        raise ValueError(
-            f"resample(res_type='fft'): length {n} has a prime factor too large for the on-chip "
-            "transform (needs N = N1*N2 with both <= 4096); use resample_poly or res_type='linear'")
-    return a.value, b.value
+    return (a.value, b.value) if rc == 0 else None
+
+
+_chirp_cache: dict[tuple, tuple] = {}
+
+
+def _chirp_tables(n: int, device):
+    """Bluestein tables of a length the four-step engine cannot factor: chirp[k] = exp(-i pi k^2 / n)
+    and the length-M spectrum of its conjugate laid out circularly, M = the power of two >= 2n - 1.
+    Built once per length on the host in float64 (k^2 mod 2n keeps the phase exact), like the
+    window and twiddle tables."""
+    key = (n, str(device))
+    hit = _chirp_cache.get(key)
+    if hit is None:
+        k = np.arange(n, dtype=np.int64)
+        c = np.exp(-1j * np.pi * ((k * k) % (2 * n)) / n)
+        m = 1 << int(2 * n - 2).bit_length()
+        if _cfft_split(m) is None:
+            raise ValueError(f"resample(res_type='fft'): length {n} is too long for the on-chip transform "
+                             "(chirp length above 4096 * 4096); use resample_poly or res_type='linear'")
+        b = np.zeros(m, np.complex128)
+        b[:n] = np.conj(c)
+        b[m - n + 1:] = np.conj(c[1:][::-1])
+        spec = np.fft.fft(b)
+        as_dev = lambda z: torch.from_numpy(np.ascontiguousarray(z.astype(np.complex64)).view(np.float32)).to(device)
+        hit = (as_dev(c), as_dev(spec), m)
+        _chirp_cache[key] = hit
+    return hit
 
 
 def _resample_fft(rows: torch.Tensor, out: torch.Tensor, post_scale: float) -> None:
-    """scipy.signal.resample on the device (reference resample.py:97,123): four-step complex
-    FFT of the whole clip, SciPy's spectrum surgery, inverse transform."""
+    """scipy.signal.resample on the device (reference resample.py:97,123): complex FFT of the whole
+    clip, SciPy's spectrum surgery, inverse transform.  Each transform runs on the four-step engine
+    directly when its length factors as N1 * N2 with both <= 4096, otherwise as a chirp-z (Bluestein)
+    convolution over the next power of two >= 2N - 1 on the same engine."""
     from .stft import _get_twiddles
 
     R, L = rows.shape
     n_out = out.shape[1]
     dev = rows.device
-    legs = _cfft_split(L) + _cfft_split(n_out)
-    tws = [_get_twiddles(n, dev) for n in legs]
-    ws = torch.empty(4 * R * max(L, n_out), dtype=torch.float32, device=dev)
-    _x.check(_x.dlib(dev).ap_resample_fft_f32(_x.ptr(rows), R, L, n_out, _x.ptr(tws[0]), _x.ptr(tws[1]),
-                                          _x.ptr(tws[2]), _x.ptr(tws[3]), _x.ptr(ws), _x.ptr(out),
-                                          _x.stream_ptr(dev)))
+    args, nmax = [], max(L, n_out)
+    for n in (L, n_out):
+        split = _cfft_split(n)
+        if split is not None:
+            args += [0, _x.ptr(_get_twiddles(split[0], dev)), _x.ptr(_get_twiddles(split[1], dev)), None, None]
+        else:
+            chirp, spec, m = _chirp_tables(n, dev)
+            m1, m2 = _cfft_split(m)
+            args += [m, _x.ptr(_get_twiddles(m1, dev)), _x.ptr(_get_twiddles(m2, dev)), _x.ptr(chirp), _x.ptr(spec)]
+            nmax = max(nmax, m)
+    ws = torch.empty(4 * R * nmax, dtype=torch.float32, device=dev)
+    _x.check(_x.dlib(dev).ap_resample_fft_chirp_f32(_x.ptr(rows), R, L, n_out, *args, _x.ptr(ws), _x.ptr(out),
+                                                _x.stream_ptr(dev)))
     if post_scale != 1.0:
         out.mul_(post_scale)        # `scale=True`: y_new *= ratio (resample.py:126-127)
 

@@ -271,15 +271,38 @@ def cfft_split(N):
     return (a.value, b.value) if rc == 0 else None
 
 
-def resample_fft(x, num):
+def chirp_tables(N):
+    """float64-built Bluestein tables (same construction as mlx-audio-primitives_amd/resample.py)."""
+    n = np.arange(N, dtype=np.int64)
+    c = np.exp(-1j * np.pi * ((n * n) % (2 * N)) / N)
+    M = 1 << int(2 * N - 2).bit_length() if N > 1 else 1
+    b = np.zeros(M, np.complex128)
+    b[:N] = np.conj(c)
+    if N > 1:
+        b[M - N + 1:] = np.conj(c[1:][::-1])
+    return np.ascontiguousarray(c.astype(np.complex64)), np.ascontiguousarray(np.fft.fft(b).astype(np.complex64)), M
+
+
+def resample_fft(x, num, force_chirp=False):
     x = np.ascontiguousarray(x, np.float32)
     B, Nx = x.shape
-    (a1, a2), (b1, b2) = cfft_split(Nx), cfft_split(num)
-    tws = [twiddles(n) for n in (a1, a2, b1, b2)]
-    ws = np.zeros(4 * B * max(Nx, num), np.float32)
+    args, alive, nmax = [], [], max(Nx, num)
+    for N in (Nx, num):
+        split = None if force_chirp else cfft_split(N)
+        if split is not None:
+            t1, t2 = twiddles(split[0]), twiddles(split[1])
+            alive += [t1, t2]
+            args += [_i64(0), _p(t1), _p(t2), None, None]
+        else:
+            c, spec, M = chirp_tables(N)
+            m1, m2 = cfft_split(M)
+            t1, t2 = twiddles(m1), twiddles(m2)
+            alive += [c, spec, t1, t2]
+            args += [_i64(M), _p(t1), _p(t2), _p(c), _p(spec)]
+            nmax = max(nmax, M)
+    ws = np.zeros(4 * B * nmax, np.float32)
     out = np.zeros((B, num), np.float32)
-    _check(lib().emu_resample_fft_f32(_p(x), _i64(B), _i64(Nx), _i64(num), _p(tws[0]), _p(tws[1]),
-                                      _p(tws[2]), _p(tws[3]), _p(ws), _p(out)))
+    _check(lib().emu_resample_fft_chirp_f32(_p(x), _i64(B), _i64(Nx), _i64(num), *args, _p(ws), _p(out)))
     return out
 
 

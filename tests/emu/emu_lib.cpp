@@ -59,6 +59,33 @@ static bool emu_launch_stft8(const ApStftParams &P, int64_t B) {
     return true;
 }
 
+struct EmuFftOps {                       // kernel launches of ap_resample_fft_compose on the CPU emulator
+    int leg(const ApCfftParams &C, int64_t B) {
+        emu_launch((unsigned)(C.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(C); });
+        return AP_OK;
+    }
+    int spectrum(const ap_float2 *X, int64_t Nx, ap_float2 *Y, int64_t num, int64_t B) {
+        emu_launch(ap_grid_1d(B * num, AP_BLOCK, kApStreamGrid), AP_BLOCK, [&] { ap_resample_spectrum_kernel(X, Nx, Y, num, B); });
+        return AP_OK;
+    }
+    int chirp_pre(const void *in, int real_in, int64_t N, const float *chirp, int conj, ap_float2 *out, int64_t M, int64_t B) {
+        emu_launch(ap_grid_1d(B * M, AP_BLOCK, kApStreamGrid), AP_BLOCK,
+                   [&] { ap_chirp_pre_kernel(in, real_in, N, reinterpret_cast<const ap_float2 *>(chirp), conj, out, M, B); });
+        return AP_OK;
+    }
+    int chirp_spec(ap_float2 *buf, const float *spec, int conj, int64_t M, int64_t B) {
+        emu_launch(ap_grid_1d(B * M, AP_BLOCK, kApStreamGrid), AP_BLOCK,
+                   [&] { ap_chirp_spec_kernel(buf, reinterpret_cast<const ap_float2 *>(spec), conj, M, B); });
+        return AP_OK;
+    }
+    int chirp_post(const ap_float2 *buf, int64_t M, const float *chirp, int conj, int64_t N, float scale, int real_out,
+                   void *out, int64_t B) {
+        emu_launch(ap_grid_1d(B * N, AP_BLOCK, kApStreamGrid), AP_BLOCK,
+                   [&] { ap_chirp_post_kernel(buf, M, reinterpret_cast<const ap_float2 *>(chirp), conj, N, scale, real_out, out, B); });
+        return AP_OK;
+    }
+};
+
 extern "C" {
 
 const char *emu_last_error(void) { return g_err; }
@@ -358,26 +385,20 @@ int emu_dct_f32(const float *x, const float *C, const float *row_scale, int64_t 
     return AP_OK;
 }
 
+int emu_resample_fft_chirp_f32(const float *x, int64_t B, int64_t Nx, int64_t num, int64_t Mx, const float *tw_x1,
+                               const float *tw_x2, const float *chirp_x, const float *spec_x, int64_t My,
+                               const float *tw_y1, const float *tw_y2, const float *chirp_y, const float *spec_y,
+                               float *ws, float *out) {
+    const ApCfftSide X = {Nx, Mx, tw_x1, tw_x2, chirp_x, spec_x};
+    const ApCfftSide Y = {num, My, tw_y1, tw_y2, chirp_y, spec_y};
+    EmuFftOps ops;
+    return ap_resample_fft_compose(ops, x, B, X, Y, ws, out);
+}
+
 int emu_resample_fft_f32(const float *x, int64_t B, int64_t Nx, int64_t num, const float *tw_x1,
                          const float *tw_x2, const float *tw_y1, const float *tw_y2, float *ws, float *out) {
-    int a1, a2, b1, b2;
-    if (ap_cfft_split(Nx, &a1, &a2) != 0 || ap_cfft_split(num, &b1, &b2) != 0)
-        AP_FAIL(AP_ERR_UNSUPPORTED, "resample(fft): unsupported length");
-    const int64_t Nmax = Nx > num ? Nx : num;
-    ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ws);
-    ap_float2 *bufB = bufA + B * Nmax;
-    ApCfftParams L1, L2;
-    int rc = ap_prepare_cfft(L1, L2, x, bufA, bufB, B, Nx, a1, a2, tw_x1, tw_x2, 0, 1, 0, 1.0f);
-    if (rc != AP_OK) return rc;
-    emu_launch((unsigned)(L1.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L1); });
-    emu_launch((unsigned)(L2.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L2); });
-    emu_launch(ap_grid_1d(B * num, AP_BLOCK, kApStreamGrid), AP_BLOCK,
-               [&] { ap_resample_spectrum_kernel(bufB, Nx, bufA, num, B); });
-    rc = ap_prepare_cfft(L1, L2, bufA, bufB, out, B, num, b1, b2, tw_y1, tw_y2, 1, 0, 1, (float)(1.0 / (double)Nx));
-    if (rc != AP_OK) return rc;
-    emu_launch((unsigned)(L1.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L1); });
-    emu_launch((unsigned)(L2.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(L2); });
-    return AP_OK;
+    return emu_resample_fft_chirp_f32(x, B, Nx, num, 0, tw_x1, tw_x2, nullptr, nullptr, 0, tw_y1, tw_y2, nullptr,
+                                      nullptr, ws, out);
 }
 
 int emu_cfft_split(int64_t N, int *N1, int *N2) { return ap_cfft_split(N, N1, N2); }

@@ -301,6 +301,17 @@ def test_emu_resample_fft_matches_scipy(Nx, num, B):
     assert eb.cfft_split(9001) is None and eb.cfft_split(22050) == (150, 147)
 
 
+@pytest.mark.parametrize("Nx,num,B,force", [(1000, 500, 2, True), (601, 907, 1, True), (6, 4, 1, True),
+                                            (10007, 5003, 1, False), (8192, 9001, 2, False), (9001, 4410, 1, False)])
+def test_emu_resample_fft_chirp_matches_scipy(Nx, num, B, force):
+    """Lengths with a prime factor > 4096 (and, forced, small ones): either transform as a chirp-z
+    (Bluestein) convolution on the four-step engine == scipy.signal.resample."""
+    import scipy.signal
+    x = np.random.default_rng(Nx + num).standard_normal((B, Nx)).astype(np.float32)
+    np.testing.assert_allclose(eb.resample_fft(x, num, force_chirp=force), scipy.signal.resample(x, num, axis=-1),
+                               rtol=1e-4, atol=2e-5)
+
+
 def test_emu_pcg64_uniform_matches_numpy_bit_for_bit():
     """Device PCG64 (128-bit LCG jump-ahead + XSL-RR) == np.random.default_rng(seed).uniform(...)"""
     for seed, n in ((42, 100000), (7, 33), (123456789, 4097)):

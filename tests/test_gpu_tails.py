@@ -97,9 +97,20 @@ def test_resample_fft_matches_scipy_fixtures_and_oracle(random_signal):
     np.testing.assert_allclose(host(ap.resample(y, 22050, 16000, scale=True)),
                                ao.resample(random_signal, 22050, 16000, scale=True), rtol=1e-4, atol=1e-4)
     assert ap.resample(y, 22050, 16000, fix=False).shape == ao.resample(random_signal, 22050, 16000, fix=False).shape
-    # a length with a prime factor > 4096 cannot be transformed on chip: loud error, no CPU fallback
-    with pytest.raises(ValueError, match="prime factor"):
-        ap.resample(dev(np.zeros(9001, np.float32)), 9001, 4500)
+
+
+@pytest.mark.parametrize("L,num,B", [(9001, 4500, 2), (10007, 5003, 1), (100003, 36283, 1), (44100, 40009, 3),
+                                     (2 * 8191, 8191, 2), (300007, 150001, 1)])
+def test_resample_fft_lengths_with_large_prime_factors(L, num, B):
+    """Lengths the four-step engine cannot factor (a prime factor > 4096) run as chirp-z convolutions on
+    it; reference resample.py:97,123 = scipy.signal.resample for any length."""
+    import scipy.signal
+    x = np.random.default_rng(L).standard_normal((B, L)).astype(np.float32)
+    got = host(ap.resample(dev(x), L, num, res_type="fft"))
+    want = scipy.signal.resample(x.astype(np.float64), num, axis=-1)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(got, ao.resample(x, L, num, res_type="fft"), rtol=1e-4, atol=5e-5)
 
 
 # ------------------------------------------------------------------ dB / DCT / MFCC
