@@ -28,6 +28,7 @@
 // whose rows have <= 4 parts; everything else stays on ap_mel2048_wave_kernel.
 // Reference: mel.py:245-352 (stft.py:130 + mel.py:344-350).
 #pragma once
+#include <type_traits>
 #include "kernels_wave.h"
 
 #define APM_WAVES 8           // waves per workgroup (2 per SIMD, 256 VGPRs each)
@@ -305,33 +306,47 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
         const int16_t *y16 = reinterpret_cast<const int16_t *>(P.y);
         ApClip clip = ap_clip_make(P.y + (IN16 ? 0 : b * P.L), IN16 ? 0 : P.L);
         ApClip16 clip16 = ap_clip16_make(y16 + (IN16 ? b * P.L : 0), IN16 ? P.L : 0);
+        // Sample pair j of the frame in hand lives in raw[(j + HOPJ rot) & 15]: with hop = 128 HOPJ, pair j of
+        // frame t + 1 is pair j + HOPJ of frame t, so the HOPJ new pairs of the next frame overwrite the HOPJ
+        // oldest registers and nothing moves.  `rot` has to be a compile-time constant for that (registers
+        // cannot be indexed), hence a loop trip of U = 16 / HOPJ frames, one copy of the body per rotation.
+        // (The earlier form shifted the 12 surviving pairs every frame: 24 v_mov_b64, 5 % of the issue slots.)
+        constexpr int U = HOPJ == 4 ? 4 : 1;
         ap_float2 raw[16];
-        auto load_frame = [&](int tt) {
+        auto load_frame = [&](int tt, auto rot_tag) {
+            constexpr int ROT = decltype(rot_tag)::value;
             const int base = tt * P.hop - P.pad;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int p = base + 2 * (lane + 64 * j);
-                raw[j] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                raw[(j + HOPJ * ROT) & 15] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
             }
         };
-        load_frame(t);
-        float acc0[APM_RUN], acc1[APM_RUN];       // the run's values of rows lane and lane + 64 (newest last)
+        load_frame(t, std::integral_constant<int, 0>());
+        // The run of finished frames (rows lane and lane + 64) waits in registers for a 32-byte store:
+        // position p8 = 4 h + rot of an 8-frame cycle (U = 4: static register, uniform half h), or a
+        // shift register (U = 1).
+        float acc0[APM_RUN], acc1[APM_RUN];
 #pragma unroll
         for (int i = 0; i < APM_RUN; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-        int nrun = 0;
+        int nrun = 0, half = 0;
+        int64_t f = f_lo;
 
-        for (int64_t f = f_lo; f < f_hi; ++f) {
+        // one frame; returns false after the last frame of the stretch
+        auto frame = [&](auto rot_tag) -> bool {
+            constexpr int ROT = decltype(rot_tag)::value;
+            constexpr int NROT = (ROT + 1) % U;
             AP_FAIR_SHARE(wave, NW, f);
             ap_float2 v[16];
             if (REGS & APM_REG_WIN) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], winr[j]);
+                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[(j + HOPJ * ROT) & 15], winr[j]);
             } else {
                 ap_float2 w[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[j], w[j]);
+                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[(j + HOPJ * ROT) & 15], w[j]);
             }
             const bool clip_ends = t + 1 == Ti;
             const bool more = f + 1 < f_hi;
@@ -343,19 +358,22 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
                 if (clip_ends) {                  // next clip starts
                     if (IN16) clip16 = ap_clip16_make(y16 + (b + 1) * P.L, P.L);
                     else clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
-                    load_frame(0);
-                } else if (HOPJ == 0) {
-                    load_frame(t + 1);
-                } else {
-                    // hop = 128 HOPJ: pair j of frame t + 1 is pair j + HOPJ of frame t - only the HOPJ
-                    // new pairs are loaded (the shared samples stay in registers across the frame)
-                    const int base = (t + 1) * P.hop - P.pad;
+                }
+                // hop = 128 HOPJ: only the HOPJ new pairs are loaded, the shared samples stay where they are;
+                // a new clip (and HOPJ = 0) loads the other pairs as well, into the same registers.  (One
+                // code path on purpose: with the full load in a branch of its own the register allocator
+                // copied all 12 surviving pairs out and back on every frame.)
+                const int base = (clip_ends ? 0 : t + 1) * P.hop - P.pad;
 #pragma unroll
-                    for (int j = 0; j < 16 - HOPJ; ++j) raw[j] = raw[j + HOPJ];
+                for (int j = 16 - HOPJ; j < 16; ++j) {
+                    const int p = base + 2 * (lane + 64 * j);
+                    raw[(j + HOPJ * NROT) & 15] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                }
+                if (HOPJ == 0 || clip_ends) {
 #pragma unroll
-                    for (int j = 16 - HOPJ; j < 16; ++j) {
+                    for (int j = 0; j < 16 - HOPJ; ++j) {
                         const int p = base + 2 * (lane + 64 * j);
-                        raw[j] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                        raw[(j + HOPJ * NROT) & 15] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
                     }
                 }
             }
@@ -405,15 +423,25 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
                 sum2[i] = sum;
                 vmax = fmaxf(vmax, cnt[i] > 0 ? sum : vmax);
             }
+            // the frame's position in the run registers, and the position of the run's first frame
+            int pos;
+            if (U == 1) {
 #pragma unroll
-            for (int i = 0; i < APM_RUN - 1; ++i) { acc0[i] = acc0[i + 1]; acc1[i] = acc1[i + 1]; }
-            acc0[APM_RUN - 1] = sum2[0];
-            acc1[APM_RUN - 1] = sum2[1];
+                for (int i = 0; i < APM_RUN - 1; ++i) { acc0[i] = acc0[i + 1]; acc1[i] = acc1[i + 1]; }
+                acc0[APM_RUN - 1] = sum2[0];
+                acc1[APM_RUN - 1] = sum2[1];
+                pos = APM_RUN - 1;
+            } else {
+                if (half) { acc0[4 + ROT] = sum2[0]; acc1[4 + ROT] = sum2[1]; }        // uniform branch
+                else { acc0[ROT] = sum2[0]; acc1[ROT] = sum2[1]; }
+                pos = 4 * half + ROT;
+            }
             ++nrun;
             AP_WAVE_SYNC();
             // ---- store the run when it is full, the clip ends or the stretch ends ---------------
-            if (nrun == APM_RUN || clip_ends || !more) {
-                // frame t - nrun + 1 + g sits in register APM_RUN - nrun + g
+            if ((U == 1 ? nrun == APM_RUN : pos == APM_RUN - 1) || clip_ends || !more) {
+                // frame t - nrun + 1 + g sits in register pos - nrun + 1 + g
+                const int first = pos - nrun + 1;
                 float *ob = P.out + b * (int64_t)M * P.T + (t - nrun + 1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -430,13 +458,26 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
                         } else {
 #pragma unroll
                             for (int g = 0; g < APM_RUN; ++g)
-                                if (g >= APM_RUN - nrun) dst[g - (APM_RUN - nrun)] = src[g];
+                                if (g >= first && g <= pos) dst[g - first] = src[g];
                         }
                     }
                 }
                 nrun = 0;
             }
             if (clip_ends) { t = 0; ++b; } else { ++t; }
+            ++f;
+            return more;
+        };
+        if (U == 1) {
+            while (frame(std::integral_constant<int, 0>())) {}
+        } else {
+            for (;;) {
+                if (!frame(std::integral_constant<int, 0>())) break;
+                if (!frame(std::integral_constant<int, 1 % U>())) break;
+                if (!frame(std::integral_constant<int, 2 % U>())) break;
+                if (!frame(std::integral_constant<int, 3 % U>())) break;
+                half ^= 1;
+            }
         }
     }
     AP_DIAG_END((int)worker);
