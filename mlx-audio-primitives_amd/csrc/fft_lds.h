@@ -56,6 +56,8 @@ AP_DEV ap_float2 ap_fma_s(ap_float2 a, float s, ap_float2 b) {                  
     return __builtin_elementwise_fma(a, ap_mk(s, s), b);
 }
 AP_DEV ap_float2 ap_mul_mi(ap_float2 a) { return ap_mk(a.y, -a.x); }                  // -i a
+AP_DEV ap_float2 ap_fma2(ap_float2 a, ap_float2 b, ap_float2 c) { return __builtin_elementwise_fma(a, b, c); }    // a*b + c
+AP_DEV ap_float2 ap_fnma2(ap_float2 a, ap_float2 b, ap_float2 c) { return __builtin_elementwise_fma(a, -b, c); }  // c - a*b
 #define AP_PK2(name, insn)                                                    \
     AP_DEV ap_float2 name(ap_float2 a, ap_float2 b) {                          \
         ap_float2 d;                                                           \
@@ -100,6 +102,8 @@ AP_DEV ap_float2 ap_scale(ap_float2 a, float s) { return ap_mk(a.x * s, a.y * s)
 AP_DEV ap_float2 ap_mul2(ap_float2 a, ap_float2 b) { return ap_mk(a.x * b.x, a.y * b.y); }
 AP_DEV ap_float2 ap_fma_s(ap_float2 a, float s, ap_float2 b) { return ap_mk(a.x * s + b.x, a.y * s + b.y); }
 AP_DEV ap_float2 ap_mul_mi(ap_float2 a) { return ap_mk(a.y, -a.x); }
+AP_DEV ap_float2 ap_fma2(ap_float2 a, ap_float2 b, ap_float2 c) { return ap_mk(a.x * b.x + c.x, a.y * b.y + c.y); }
+AP_DEV ap_float2 ap_fnma2(ap_float2 a, ap_float2 b, ap_float2 c) { return ap_mk(c.x - a.x * b.x, c.y - a.y * b.y); }
 AP_DEV ap_float2 ap_add_mi(ap_float2 a, ap_float2 b) { return ap_mk(a.x + b.y, a.y - b.x); }
 AP_DEV ap_float2 ap_sub_mi(ap_float2 a, ap_float2 b) { return ap_mk(a.x - b.y, a.y + b.x); }
 AP_DEV ap_float2 ap_add_conj(ap_float2 a, ap_float2 b) { return ap_mk(a.x + b.x, a.y - b.y); }
@@ -210,18 +214,45 @@ struct ApButterfly<8> {
     }
 };
 
+// radix-4 butterfly of the products x_i w_i (w applied per component: a window on packed real pairs):
+// the first level's sums and differences take the second product as an FMA - 6 instructions for the 4
+// multiplies and 4 additions
+AP_DEV void ap_fft4_weighted(const ap_float2 &x0, const ap_float2 &w0, const ap_float2 &x1, const ap_float2 &w1,
+                             const ap_float2 &x2, const ap_float2 &w2, const ap_float2 &x3, const ap_float2 &w3,
+                             ap_float2 &a0, ap_float2 &a1, ap_float2 &a2, ap_float2 &a3) {
+    const ap_float2 m0 = ap_mul2(x0, w0), m1 = ap_mul2(x1, w1);
+    const ap_float2 t0 = ap_fma2(x2, w2, m0), t1 = ap_fnma2(x2, w2, m0);
+    const ap_float2 t2 = ap_fma2(x3, w3, m1), e = ap_fnma2(x3, w3, m1);
+    a0 = ap_add(t0, t2);
+    a2 = ap_sub(t0, t2);
+    a1 = ap_add_mi(t1, e);
+    a3 = ap_sub_mi(t1, e);
+}
+
 template <>
 struct ApButterfly<16> {
     static AP_DEV void run(ap_float2 *v) {
-        // cos/sin(2 pi m / 16), m = 1,2,3 (others by symmetry)
-        const float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
-        const float H = 0.70710678118654752440f;
         ap_float2 a[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             a[r][0] = v[r]; a[r][1] = v[r + 4]; a[r][2] = v[r + 8]; a[r][3] = v[r + 12];
             ap_fft4(a[r][0], a[r][1], a[r][2], a[r][3]);
         }
+        finish(a, v);
+    }
+    // v = DFT16 of (x[i] w[i]), the weights folded into the first level
+    static AP_DEV void run_weighted(const ap_float2 *x, const ap_float2 *w, ap_float2 *v) {
+        ap_float2 a[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            ap_fft4_weighted(x[r], w[r], x[r + 4], w[r + 4], x[r + 8], w[r + 8], x[r + 12], w[r + 12],
+                             a[r][0], a[r][1], a[r][2], a[r][3]);
+        finish(a, v);
+    }
+    static AP_DEV void finish(ap_float2 (&a)[4][4], ap_float2 *v) {
+        // cos/sin(2 pi m / 16), m = 1,2,3 (others by symmetry)
+        const float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+        const float H = 0.70710678118654752440f;
         // twiddle a[r][p] *= W16^(r*p); entry (c,s) means c - i s
         // r=1: p=1 (C1,S1) p=2 (H,H) p=3 (S1,C1)
         a[1][1] = ap_mul_fw_c(a[1][1], C1, S1);

@@ -81,30 +81,34 @@ AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
 // the 2 wait states between an outside VALU write and the first DPP read of that register, and
 // inside every DPP read sits >= 14 instructions behind the write of its register.  The halves of
 // the complex register pairs are named directly (v[i].x / v[i].y): no unpacking moves.
-#define APM_S1(i) "v_fmac_f32_dpp %" #i ", %" #i ", %17 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-#define APM_S2(i) "v_fmac_f32_dpp %" #i ", %" #i ", %18 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-#define APM_ROT(ix, iy)                                  \
-    "v_mov_b32 %16, %" #ix "\n\t"                       \
-    "v_cndmask_b32 %" #ix ", %" #ix ", %" #iy ", %19\n\t" \
-    "v_cndmask_b32 %" #iy ", %" #iy ", -%16, %19\n\t"
+// lane 3 of the quad: (x, y) -> (y, -x), written to a fresh register pair (operands nx, ny) that stage 2
+// carries on with: no copy of the old x, and the pair stays a pair for the packed code that follows.
+#define APM_ROT(ix, iy, nx, ny)                            \
+    "v_cndmask_b32 %" #nx ", %" #ix ", %" #iy ", %34\n\t"  \
+    "v_cndmask_b32 %" #ny ", %" #iy ", -%" #ix ", %34\n\t"
+#define APM_S2N(i) "v_fmac_f32_dpp %" #i ", %" #i ", %33 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define APM_S1N(i) "v_fmac_f32_dpp %" #i ", %" #i ", %32 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
 AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
-    float t;
+    ap_float2 n[8];
     const unsigned long long rot_mask = 0x8888888888888888ull;      // lane 3 of every quad
     asm volatile(
         "s_nop 1\n\t"
-        APM_S1(0) APM_S1(1) APM_S1(2) APM_S1(3) APM_S1(4) APM_S1(5) APM_S1(6) APM_S1(7)
-        APM_S1(8) APM_S1(9) APM_S1(10) APM_S1(11) APM_S1(12) APM_S1(13) APM_S1(14) APM_S1(15)
-        APM_ROT(0, 1) APM_ROT(2, 3) APM_ROT(4, 5) APM_ROT(6, 7)
-        APM_ROT(8, 9) APM_ROT(10, 11) APM_ROT(12, 13) APM_ROT(14, 15)
-        APM_S2(0) APM_S2(1) APM_S2(2) APM_S2(3) APM_S2(4) APM_S2(5) APM_S2(6) APM_S2(7)
-        APM_S2(8) APM_S2(9) APM_S2(10) APM_S2(11) APM_S2(12) APM_S2(13) APM_S2(14) APM_S2(15)
+        APM_S1N(0) APM_S1N(1) APM_S1N(2) APM_S1N(3) APM_S1N(4) APM_S1N(5) APM_S1N(6) APM_S1N(7)
+        APM_S1N(8) APM_S1N(9) APM_S1N(10) APM_S1N(11) APM_S1N(12) APM_S1N(13) APM_S1N(14) APM_S1N(15)
+        APM_ROT(0, 1, 16, 17) APM_ROT(2, 3, 18, 19) APM_ROT(4, 5, 20, 21) APM_ROT(6, 7, 22, 23)
+        APM_ROT(8, 9, 24, 25) APM_ROT(10, 11, 26, 27) APM_ROT(12, 13, 28, 29) APM_ROT(14, 15, 30, 31)
+        APM_S2N(16) APM_S2N(17) APM_S2N(18) APM_S2N(19) APM_S2N(20) APM_S2N(21) APM_S2N(22) APM_S2N(23)
+        APM_S2N(24) APM_S2N(25) APM_S2N(26) APM_S2N(27) APM_S2N(28) APM_S2N(29) APM_S2N(30) APM_S2N(31)
         : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
           "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y),
-          "=&v"(t)
+          "=&v"(n[0].x), "=&v"(n[0].y), "=&v"(n[1].x), "=&v"(n[1].y), "=&v"(n[2].x), "=&v"(n[2].y), "=&v"(n[3].x), "=&v"(n[3].y),
+          "=&v"(n[4].x), "=&v"(n[4].y), "=&v"(n[5].x), "=&v"(n[5].y), "=&v"(n[6].x), "=&v"(n[6].y), "=&v"(n[7].x), "=&v"(n[7].y)
         : "v"(m.c1), "v"(m.c2), "s"(rot_mask));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = n[i];
 }
-#undef APM_S1
-#undef APM_S2
+#undef APM_S1N
+#undef APM_S2N
 #undef APM_ROT
 #endif
 
@@ -123,19 +127,22 @@ AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
 #define APM_REGS (APM_REG_WIN | APM_REG_SPLIT)
 
 // forward transform of apw_forward with the fmac-DPP quad stage; tw2row holds sg * W_64^(a c)
+// (the samples x and the window pairs w go in separately: the window rides on the first butterfly level)
 template <int REGS>
-AP_DEV void apm_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ap_float2 *tw2row,
-                        const ap_float2 (&t1r)[16], const ap_float2 (&t2r)[16], const ApwLane &c, const ApmLane &m) {
+AP_DEV void apm_forward(const ap_float2 (&x)[16], const ap_float2 (&w)[16], ap_float2 *X, const ap_float2 *TW1,
+                        const ap_float2 *tw2row, const ap_float2 (&t1r)[16], const ap_float2 (&t2r)[16],
+                        const ApwLane &c, const ApmLane &m) {
     const int lane = c.lane;
+    ap_float2 v[16];
     if (REGS & APM_REG_TW1) {
-        ApButterfly<16>::run(v);
+        ApButterfly<16>::run_weighted(x, w, v);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1r[k]);
     } else {
         ap_float2 t1[16];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];
-        ApButterfly<16>::run(v);
+        ApButterfly<16>::run_weighted(x, w, v);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
     }
@@ -337,21 +344,22 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
             constexpr int ROT = decltype(rot_tag)::value;
             constexpr int NROT = (ROT + 1) % U;
             AP_FAIR_SHARE(wave, NW, f);
-            ap_float2 v[16];
-            if (REGS & APM_REG_WIN) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[(j + HOPJ * ROT) & 15], winr[j]);
-            } else {
-                ap_float2 w[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) w[j] = WIN[lane + 64 * j];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = ap_mul2(raw[(j + HOPJ * ROT) & 15], w[j]);
-            }
             const bool clip_ends = t + 1 == Ti;
             const bool more = f + 1 < f_hi;
-            AP_SCHED_FENCE();
-            apm_forward<REGS>(v, X, TW1, lc.tw2row, t1r, t2r, lc, lm);
+            {
+                ap_float2 xs[16], ws[16];         // renamings: no instructions
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xs[j] = raw[(j + HOPJ * ROT) & 15];
+                if (REGS & APM_REG_WIN) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) ws[j] = winr[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) ws[j] = WIN[lane + 64 * j];
+                }
+                AP_SCHED_FENCE();
+                apm_forward<REGS>(xs, ws, X, TW1, lc.tw2row, t1r, t2r, lc, lm);
+            }
             // The next frame of this wave's stretch, in flight during split + contraction
             AP_SCHED_FENCE();
             if (more) {
