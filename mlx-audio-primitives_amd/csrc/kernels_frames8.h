@@ -237,7 +237,9 @@ AP_DEV void apq_group_loop(const ApFrames8Params &P, const ApqLane &Ln, const ap
         for (int r = 0; r < R; ++r) raw[r] = ap_clip_load2(clip, base + 16 * r);
     };
     load_group(t0);
-    for (int64_t grp = grp_lo; grp < grp_hi; ++grp) {
+    // (the loop leaves through `more`: were the prefetch skipped on a path that re-enters the loop, the
+    // register allocator would copy all R pairs at that merge)
+    for (int64_t grp = grp_lo;; ++grp) {
         ap_float2 v[R];
         if (WIN_REGS) {
 #pragma unroll
@@ -250,18 +252,21 @@ AP_DEV void apq_group_loop(const ApFrames8Params &P, const ApqLane &Ln, const ap
             for (int r = 0; r < R; ++r) v[r] = ap_mul2(raw[r], w[r]);
         }
         const bool clip_ends = t0 + 8 >= Ti;
+        // the windowed values exist before the prefetch is issued, so the samples' registers are free for
+        // it (otherwise the multiplies sink below the loads and the prefetch needs a second register set
+        // plus R copies per group)
+#pragma unroll
+        for (int r = 0; r < R; ++r) AP_PIN(v[r]);
         AP_SCHED_FENCE();
-        if (grp + 1 < grp_hi) {                           // next group, in flight during this one
-            if (clip_ends) {
-                clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
-                load_group(0);
-            } else {
-                load_group(t0 + 8);
-            }
+        const bool more = grp + 1 < grp_hi;
+        if (more) {                                       // next group, in flight during this one
+            if (clip_ends) clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
+            load_group(clip_ends ? 0 : t0 + 8);
         }
         AP_SCHED_FENCE();
         apq_transform<R>(v, Trow, Ln);
         body(v, b, t0);
+        if (!more) break;
         if (clip_ends) { t0 = 0; ++b; } else { t0 += 8; }
     }
 }

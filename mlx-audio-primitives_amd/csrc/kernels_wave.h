@@ -42,8 +42,12 @@ __device__ unsigned long long ap_diag_stamps[4 * 256 * 16];
 #ifdef AP_HOST_EMU
 #define AP_WAVE_SYNC() emu_wave_sync()
 #define AP_SCHED_FENCE() do {} while (0)
+#define AP_PIN(x) do {} while (0)
 #else
 #define AP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the value has to exist here: keeps a pure computation from being sunk past a later branch (where it
+// would stretch the live ranges of its inputs across that branch)
+#define AP_PIN(x) asm volatile("" : "+v"(x))
 // wave-private LDS hand-off: the DS unit executes one wave's instructions in order, so
 // only the compiler has to be kept from moving LDS accesses across this point.
 #define AP_WAVE_SYNC()                                          \
