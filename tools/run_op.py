@@ -1,5 +1,5 @@
 """Run one operator a few times on the headline-sized batch (for rocprofv3 passes).
-usage: python3 tools/run_op.py {stft|istft|mel|mel1024|whisper|gl|mfcc|resample|resfft|reslin} [reps]"""
+usage: python3 tools/run_op.py {stft|istft|mel|mel1024|mel512|stft512|whisper|gl|mfcc|resample|resfft|reslin} [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,6 +26,12 @@ elif op == "mfcc":
 elif op == "mel1024":
     y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
     fn = lambda: ap.melspectrogram(y, sr=22050, n_fft=1024, hop_length=256, n_mels=80)
+elif op == "mel512":
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.melspectrogram(y, sr=22050, n_fft=512, hop_length=128, n_mels=64)
+elif op == "stft512":
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.stft(y, n_fft=512, hop_length=128)
 elif op == "gl":
     y = torch.randn((64, 110250), device="cuda", generator=g) * 0.1
     S = ap.magnitude(ap.stft(y))
