@@ -359,6 +359,18 @@ int ap_spectral_stats_f32(const float *S /*dev*/, int is_complex, int64_t B, int
                           float p, int norm, float roll_percent, float amin, float *centroid /*dev or NULL*/,
                           float *bandwidth, float *rolloff, float *flatness, void *stream);
 
+/* The same statistics straight from the audio for n_fft = 2048 (reference features.py:24-55: every
+ * feature call runs its own STFT first): transform, |X|^power and the per-frame reductions in ONE kernel,
+ * the complex spectrum never reaches HBM.  ap_spectral_audio_fused: 1 when the shape is served (n_fft
+ * 2048, center=False or constant padding with an even hop); otherwise use ap_stft_f32 + ap_spectral_stats_f32.
+ * Arguments as ap_stft_f32 + ap_spectral_stats_f32 (no centroid_in). */
+int ap_spectral_audio_fused(int64_t L, int n_fft, int hop, int center, int pad_mode);
+int ap_spectral_audio_f32(const float *y /*dev (B,L)*/, int64_t B, int64_t L, int n_fft, int hop,
+                          const float *window, const float *tw, int center, int pad_mode, int64_t T,
+                          const float *freq /*dev (n_fft/2+1)*/, float power, float p, int norm,
+                          float roll_percent, float amin, float *centroid, float *bandwidth,
+                          float *rolloff, float *flatness /*dev (B,T) or NULL*/, void *stream);
+
 /* rms(y, frame_length, hop_length, center, pad_mode) and zero_crossing_rate(...) —
  * framing.py:81-150, features.py:598-722: per frame sqrt(mean x^2) and the fraction of samples
  * i >= 1 of the frame with (x[i] >= 0) != (x[i-1] >= 0).  pad = frame_length / 2 if center else 0,

@@ -302,6 +302,35 @@ static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, 
     return AP_OK;
 }
 
+// fused spectral statistics from audio (kernels_mel2048.h, ap_spec2048_run_kernel): n_fft = 2048, sample
+// loads that stand in for constant padding.  Returns 1 when the kernel does not apply.
+static inline int ap_prepare_spec_run(ApSpecWaveParams &W, const ApStftParams &P, int64_t B, int n_waves,
+                                      int x_complex, int *grid) {
+    if (P.plan.n != 2048 || !ap_clip_loads_ok(P)) return 1;
+    if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.L = P.L;
+    W.T = P.T;
+    W.n_clips = B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    W.hopj = P.hop == 512 ? 4 : 0;
+    int off = n_waves * x_complex * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    const int64_t n_frames = B * P.T;
+    int64_t g = (n_frames + (int64_t)n_waves * 8 - 1) / ((int64_t)n_waves * 8);
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // Eight-frames-per-wave kernels (kernels_frames8.h): n_fft = 16 R, R in {16, 25, 32}.  The geometry
 // (block stride, plane floats, weight row floats, window in LDS) comes from ApqGeom<R> at the call site.
 // Returns 1 when the kernel does not apply.

@@ -33,6 +33,19 @@ struct ApMelWaveParams {
     int otile_stride;          // floats between the frames of a wave's [APW_G][n_mels] output tile (= 4 mod 32)
 };
 
+// ---- n_fft = 2048 spectral statistics straight from the audio (kernels_mel2048.h) ----------------
+struct ApSpecWaveParams {
+    const float *y;            // (B, L)
+    const float *window;       // (2048)
+    const ap_float2 *tw;       // (2048)
+    const float *freq;         // (1025) bin centres
+    float *centroid, *bandwidth, *rolloff, *flatness;      // (B, T) each, any may be NULL
+    int64_t L, T, n_clips;
+    int hop, pad, hopj, norm;
+    float power, p, roll_percent, amin;
+    int off_tw2, off_tw1, off_win, lds_bytes;
+};
+
 // ---- n_fft = 2048 STFT (complex output) wave kernel -----------------------------------
 #define APS_WAVES 8          // waves per workgroup = frames per group (64-byte row segments of (B,F,T))
 #define APS_OB_ROW 9         // complex slots per row of the transpose buffer (8 frames + 1 pad)

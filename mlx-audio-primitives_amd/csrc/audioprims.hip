@@ -150,6 +150,26 @@ static int ap_launch_stft8(const ApStftParams &P, int64_t B, void *stream, bool 
     return ap_check_launch("ap_stft_f32(frames8)");
 }
 
+template <int PMODE, int HOPJ, int FLAT, int PGEN>
+static int ap_launch_spec_run4(const ApSpecWaveParams &W, int grid, void *stream) {
+    int rc = ap_allow_lds(ap_spec2048_run_kernel<PMODE, HOPJ, FLAT, PGEN>, W.lds_bytes);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL((ap_spec2048_run_kernel<PMODE, HOPJ, FLAT, PGEN>), dim3(grid), dim3(64 * APM_WAVES), W.lds_bytes,
+                       (hipStream_t)stream, W);
+    return ap_check_launch("ap_spectral_audio_f32");
+}
+
+// the common shapes get their own instantiation; power not in {1, 2}, a bandwidth exponent != 2 and other
+// hops share the general ones
+template <int PMODE, int FLAT>
+static int ap_launch_spec_run(const ApSpecWaveParams &W, int grid, void *stream) {
+    const bool pgen = W.bandwidth && W.p != 2.0f;
+    if (W.hopj == 4) return pgen ? ap_launch_spec_run4<PMODE, 4, FLAT, 1>(W, grid, stream)
+                                 : ap_launch_spec_run4<PMODE, 4, FLAT, 0>(W, grid, stream);
+    return pgen ? ap_launch_spec_run4<PMODE, 0, FLAT, 1>(W, grid, stream)
+                : ap_launch_spec_run4<PMODE, 0, FLAT, 0>(W, grid, stream);
+}
+
 extern "C" {
 
 int ap_version(void) { return 100; }
@@ -761,6 +781,40 @@ int ap_spectral_stats_f32(const float *S, int is_complex, int64_t B, int64_t F, 
     hipLaunchKernelGGL(ap_spectral_stats_kernel, dim3((unsigned)(P.tiles_per_clip * B)), dim3(APF_TX * APF_TY), 0,
                        (hipStream_t)stream, P);
     return ap_check_launch("ap_spectral_stats_f32");
+}
+
+int ap_spectral_audio_fused(int64_t L, int n_fft, int hop, int center, int pad_mode) {
+    if (n_fft != 2048 || hop <= 0 || L <= 0) return 0;
+    const int pad = center ? n_fft / 2 : 0;
+    if (pad != 0 && (pad_mode != AP_PAD_CONSTANT || (hop & 1))) return 0;
+    if (!center && L < n_fft) return 0;
+    return std::getenv("AP_SPEC_TWO_KERNELS") ? 0 : 1;      // A/B switch: keep the STFT + statistics route
+}
+
+int ap_spectral_audio_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                          const float *tw, int center, int pad_mode, int64_t T, const float *freq, float power,
+                          float p, int norm, float roll_percent, float amin, float *centroid, float *bandwidth,
+                          float *rolloff, float *flatness, void *stream) {
+    if (!freq) AP_FAIL(AP_ERR_INVALID, "spectral features: NULL buffer");
+    if (roll_percent < 0.0f || roll_percent > 1.0f) AP_FAIL(AP_ERR_INVALID, "roll_percent must be between 0 and 1");
+    if (!(p > 0.0f)) AP_FAIL(AP_ERR_INVALID, "p must be positive");
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
+    if (rc != AP_OK) return rc;
+    if (!centroid && !bandwidth && !rolloff && !flatness) return AP_OK;
+    ApSpecWaveParams W;
+    int grid = 0;
+    if (!ap_spectral_audio_fused(L, n_fft, hop, center, pad_mode) ||
+        ap_prepare_spec_run(W, P, B, APM_WAVES, APW_X_COMPLEX, &grid) != AP_OK)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "spectral features from audio: shape not served by the fused kernel");
+    W.freq = freq;
+    W.centroid = centroid; W.bandwidth = bandwidth; W.rolloff = rolloff; W.flatness = flatness;
+    W.power = power; W.p = p; W.norm = norm; W.roll_percent = roll_percent; W.amin = amin;
+    if (flatness)
+        return power == 2.0f ? ap_launch_spec_run<2, 1>(W, grid, stream)
+               : power == 1.0f ? ap_launch_spec_run<1, 1>(W, grid, stream) : ap_launch_spec_run<0, 1>(W, grid, stream);
+    return power == 2.0f ? ap_launch_spec_run<2, 0>(W, grid, stream)
+           : power == 1.0f ? ap_launch_spec_run<1, 0>(W, grid, stream) : ap_launch_spec_run<0, 0>(W, grid, stream);
 }
 
 int ap_frame_stats_f32(const float *y, int64_t B, int64_t L, int frame_length, int hop, int center, int pad_mode,

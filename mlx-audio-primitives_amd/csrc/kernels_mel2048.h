@@ -500,3 +500,210 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Spectral centroid / bandwidth / rolloff / flatness of every frame straight from the audio, n_fft = 2048
+// (reference features.py:57-442: an STFT, |.|, |.|^p and sum / cumsum / argmax chains per call).  The
+// transform, the paired split and the |X|^p plane are those of the mel run kernel above; instead of the
+// filterbank contraction the wave reduces its frame's 1025 plane values: lane l owns the 16 contiguous
+// bins 16 l .. 16 l + 15 (lane 63 bin 1024 as well), sums them, and the 64 lane sums are combined with
+// wave shuffles; the rolloff lane is found from an exclusive scan of the lane sums.  Nothing but the
+// samples is read from HBM and 4-16 bytes per frame are written: the complex spectrum (8.2 KB per frame,
+// written and read back by the two-kernel route of kernels_features.h) never exists.
+// ---------------------------------------------------------------------------------------------
+#ifdef AP_HOST_EMU
+AP_DEV float apm_lane_xor(float x, int mask) { return emu_lane_xor(x, mask); }
+AP_DEV float apm_lane_up(float x, int d, int lane) { return emu_lane_perm(x, lane - d); }
+#else
+AP_DEV float apm_lane_xor(float x, int mask) { return __shfl_xor(x, mask, 64); }
+AP_DEV float apm_lane_up(float x, int d, int lane) { return __shfl_up(x, d, 64); }
+#endif
+AP_DEV float apm_wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += apm_lane_xor(x, off);
+    return x;
+}
+
+// FLAT: flatness wanted (17 logs per lane and frame); PGEN: bandwidth exponent p != 2 (powf in the loop -
+// a template flag so that the usual p = 2 build stays inside the instruction cache)
+template <int PMODE, int HOPJ, int FLAT, int PGEN = 0, int NW = APM_WAVES, int REGS = APM_REGS>
+__global__ void __launch_bounds__(64 * NW, NW / 4) ap_spec2048_run_kernel(ApSpecWaveParams P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
+    ap_float2 *TW2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);
+    float *pp = reinterpret_cast<float *>(X);                 // |X|^p plane of this wave (floats 0..1024)
+    apw_fill_tables(TW2, reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid, 64 * NW);
+    AP_LDS_BARRIER();
+    if (tid < 64) {       // fold the quad stage's signs s1 s2 of row a = tid >> 4 into its twiddles
+        const int a = tid >> 4;
+        const float sg = (a == 1 || a == 2) ? -1.0f : 1.0f;
+        TW2[a * 17 + (tid & 15)] = ap_scale(TW2[a * 17 + (tid & 15)], sg);
+    }
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    const ApmLane lm = apm_lane_init(lane);
+    ap_float2 winr[16], t1r[16], t2r[16], wsp[8];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        winr[j] = (REGS & APM_REG_WIN) ? reinterpret_cast<const ap_float2 *>(P.window)[lane + 64 * j] : ap_mk(0.0f, 0.0f);
+        t1r[j] = (REGS & APM_REG_TW1) ? P.tw[(2 * lane * j) & 2047] : ap_mk(0.0f, 0.0f);
+        t2r[j] = (REGS & APM_REG_TW2) ? ap_scale(P.tw[32 * (lane & 3) * j], lm.sg) : ap_mk(0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        wsp[r] = (REGS & APM_REG_SPLIT) ? ap_scale(P.tw[lane + 64 * r], 0.5f) : ap_mk(0.0f, 0.0f);
+    float fk[17];                                             // bin centres of this lane's bins
+#pragma unroll
+    for (int i = 0; i < 16; ++i) fk[i] = P.freq[16 * lane + i];
+    fk[16] = lane == 63 ? P.freq[APW_NC] : 0.0f;
+    AP_LDS_BARRIER();
+
+    const int64_t worker = (int64_t)blockIdx.x * NW + wave;
+    const int64_t n_workers = (int64_t)gridDim.x * NW;
+    const int64_t n_frames = P.n_clips * P.T;
+    const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
+    const int Ti = (int)P.T;
+    if (f_lo >= f_hi) return;
+    int64_t b = f_lo / P.T;
+    int t = (int)(f_lo - b * P.T);
+    ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+    constexpr int U = HOPJ == 4 ? 4 : 1;                      // see ap_mel2048_run_kernel
+    ap_float2 raw[16];
+    auto load_frame = [&](int tt, auto rot_tag) {
+        constexpr int ROT = decltype(rot_tag)::value;
+        const int base = tt * P.hop - P.pad;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) raw[(j + HOPJ * ROT) & 15] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+    };
+    load_frame(t, std::integral_constant<int, 0>());
+    int64_t f = f_lo;
+    const float F_all = (float)(APW_NC + 1);
+
+    auto frame = [&](auto rot_tag) -> bool {
+        constexpr int ROT = decltype(rot_tag)::value;
+        constexpr int NROT = (ROT + 1) % U;
+        const bool clip_ends = t + 1 == Ti;
+        const bool more = f + 1 < f_hi;
+        {
+            ap_float2 xs[16], ws[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xs[j] = raw[(j + HOPJ * ROT) & 15];
+            if (REGS & APM_REG_WIN) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ws[j] = winr[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ws[j] = WIN[lane + 64 * j];
+            }
+            AP_SCHED_FENCE();
+            apm_forward<REGS>(xs, ws, X, TW1, lc.tw2row, t1r, t2r, lc, lm);
+        }
+        AP_SCHED_FENCE();
+        if (more) {
+            if (clip_ends) clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
+            const int base = (clip_ends ? 0 : t + 1) * P.hop - P.pad;
+#pragma unroll
+            for (int j = 16 - HOPJ; j < 16; ++j)
+                raw[(j + HOPJ * NROT) & 15] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+            if (HOPJ == 0 || clip_ends) {
+#pragma unroll
+                for (int j = 0; j < 16 - HOPJ; ++j)
+                    raw[(j + HOPJ * NROT) & 15] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+            }
+        }
+        AP_SCHED_FENCE();
+        {
+            ap_float2 xk[8], xm[8], zh;
+            apm_split<REGS>(X, lc, wsp, xk, xm, zh);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int k = lane + 64 * r;
+                pp[k] = apw_pow2x<PMODE>(xk[r].x, xk[r].y, P.power);
+                pp[APW_NC - k] = apw_pow2x<PMODE>(xm[r].x, xm[r].y, P.power);
+            }
+            if (lane == 0) pp[APW_NC / 2] = apw_pow2x<PMODE>(zh.x, zh.y, P.power);
+        }
+        AP_WAVE_SYNC();
+        // ---- this lane's 16 (17) contiguous bins -------------------------------------------
+        float v[17];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const ap_float4 a = reinterpret_cast<const ap_float4 *>(pp)[4 * lane + q4];
+            v[4 * q4] = a.x; v[4 * q4 + 1] = a.y; v[4 * q4 + 2] = a.z; v[4 * q4 + 3] = a.w;
+        }
+        v[16] = lane == 63 ? pp[APW_NC] : 0.0f;
+        AP_WAVE_SYNC();                           // the plane is free for the next frame's transform
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) { s0 += v[i]; s1 = fmaf(fk[i], v[i], s1); }
+        const float tot = apm_wave_sum(s0), tf = apm_wave_sum(s1);
+        const float cen = tf / (tot + 1e-10f);
+        const int64_t o = b * P.T + t;
+        if (P.centroid && lane == 0) P.centroid[o] = cen;
+        if (FLAT) {                               // features.py:427-437: exp(mean log max(S, amin)) / mean max(S, amin)
+            float sl = 0.0f, sa = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) {
+                const float c = fmaxf(v[i], P.amin);
+                if (i < 16 || lane == 63) { sl += logf(c); sa += c; }
+            }
+            const float tl = apm_wave_sum(sl), ta = apm_wave_sum(sa);
+            if (P.flatness && lane == 0) P.flatness[o] = expf(tl / F_all) / (ta / F_all + 1e-10f);
+        }
+        if (P.bandwidth) {                        // features.py:242-266
+            float dev = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) {
+                const float d = fabsf(fk[i] - cen);
+                dev = fmaf(v[i], PGEN ? powf(d, P.p) : d * d, dev);
+            }
+            float w = apm_wave_sum(dev);
+            if (P.norm) w = w / (tot + 1e-10f);
+            if (lane == 0) P.bandwidth[o] = PGEN ? powf(w, 1.0f / P.p) : sqrtf(w);
+        }
+        if (P.rolloff) {                          // features.py:342-360: first bin whose running sum reaches the threshold
+            float incl = s0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float up = apm_lane_up(incl, d, lane);
+                if (lane >= d) incl += up;
+            }
+            const float before = incl - s0;
+            const float thr = tot * P.roll_percent;
+            const bool mine = (before + s0 >= thr) && (lane == 0 || before < thr);
+            float run = before, fsel = lane == 63 ? fk[16] : fk[15];
+            bool found = false;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) {
+                if (i < 16 || lane == 63) {
+                    run += v[i];
+                    if (!found && run >= thr) { found = true; fsel = fk[i]; }
+                }
+            }
+            // lowest candidate of the wave (the tree-ordered scan is monotone only up to rounding, so there
+            // may be none or two); no candidate: the last bin; sums that never reach thr (NaNs): bin 0
+            float cand = (mine && found) ? fsel : INFINITY;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cand = fminf(cand, apm_lane_xor(cand, off));
+            const float last = apm_lane_xor(fk[16], 63);               // lane 0 gets lane 63's bin 1024
+            if (lane == 0) P.rolloff[o] = !(tot >= thr) ? fk[0] : (cand < INFINITY ? cand : last);
+        }
+        if (clip_ends) { t = 0; ++b; } else { ++t; }
+        ++f;
+        return more;
+    };
+    if (U == 1) {
+        while (frame(std::integral_constant<int, 0>())) {}
+    } else {
+        for (;;) {
+            if (!frame(std::integral_constant<int, 0>())) break;
+            if (!frame(std::integral_constant<int, 1 % U>())) break;
+            if (!frame(std::integral_constant<int, 2 % U>())) break;
+            if (!frame(std::integral_constant<int, 3 % U>())) break;
+        }
+    }
+}

@@ -2,9 +2,11 @@
 (spectral_centroid / spectral_bandwidth / spectral_rolloff / spectral_flatness /
 zero_crossing_rate).
 
-From audio, the chain is the fused STFT kernel followed by ONE statistics kernel that takes |X|
-(and |X|**power) on load from the complex spectrum — the reference's magnitude / power / sum /
-cumsum / argmax tensors (features.py:24-55,115-134,342-360) are never materialised.  From a given
+From audio at n_fft = 2048 (the default) ONE kernel goes from the samples to the statistics - the
+spectrum is never written (csrc/kernels_mel2048.h, ap_spec2048_run_kernel).  Other shapes chain the fused
+STFT kernel and ONE statistics kernel that takes |X| (and |X|**power) on load from the complex
+spectrum — the reference's magnitude / power / sum / cumsum / argmax tensors
+(features.py:24-55,115-134,342-360) are never materialised.  From a given
 spectrogram S the same kernel reads S once.  ``spectral_contrast`` (a host NumPy sort per octave band
 in the reference, features.py:445-595) is outside the hot path and not built.
 """
@@ -31,6 +33,45 @@ def _get_frequencies(sr: int, n_fft: int, device) -> torch.Tensor:
     return t
 
 
+def _spectral_from_audio(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, freq, power, want,
+                         centroid, p, norm, roll_percent, amin):
+    """One kernel from the samples to the statistics (n_fft = 2048, constant padding): the complex
+    spectrum is never written.  Returns None when the shape is not served (the caller then runs the
+    fused STFT kernel + the statistics kernel)."""
+    from .stft import _frame_count, _get_padded_window, _get_twiddles, _resolve_stft_args
+
+    if centroid is not None or n_fft != 2048:
+        return None
+    hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
+    y = _x.to_device_f32(y)
+    one_d = y.ndim == 1
+    if one_d:
+        y = y[None, :]
+    if y.ndim != 2 or y.shape[0] == 0 or y.shape[1] == 0:
+        return None
+    B, L = y.shape
+    if pad_mode not in _x.PAD_MODES:
+        return None
+    if not _x.lib().ap_spectral_audio_fused(L, int(n_fft), int(hop_length), int(bool(center)), _x.PAD_MODES[pad_mode]):
+        return None
+    dev = y.device
+    F = n_fft // 2 + 1
+    freq = _get_frequencies(sr, n_fft, dev) if freq is None else _x.to_device_f32(freq, dev)
+    if freq.ndim != 1 or freq.shape[0] != F:
+        raise ValueError(f"freq must be 1D with {F} entries (freq_bins), got shape {tuple(freq.shape)}")
+    T = _frame_count(L, n_fft, hop_length, center, pad_mode)
+    win = _get_padded_window(window, win_length, n_fft, dev)
+    tw = _get_twiddles(n_fft, dev)
+    outs = {k: torch.empty((B, 1, T), dtype=torch.float32, device=dev) for k in want}
+    g = lambda k: _x.ptr(outs[k]) if k in outs else None  # noqa: E731
+    _x.check(_x.dlib(dev).ap_spectral_audio_f32(
+        _x.ptr(y.contiguous()), B, L, int(n_fft), int(hop_length), _x.ptr(win), _x.ptr(tw), int(bool(center)),
+        _x.PAD_MODES[pad_mode], T, _x.ptr(freq.contiguous()), float(power), float(p), int(bool(norm)),
+        float(roll_percent), float(amin), g("centroid"), g("bandwidth"), g("rolloff"), g("flatness"),
+        _x.stream_ptr(dev)))
+    return {k: (v[0] if one_d else v) for k, v in outs.items()}
+
+
 def _spectral(y, S, sr, n_fft, hop_length, win_length, window, center, pad_mode, freq, power=1.0,
               want=(), centroid=None, p=2.0, norm=True, roll_percent=0.85, amin=1e-10):
     """Run the statistics kernel; returns {name: (1,T) | (B,1,T) tensor} for the names in `want`."""
@@ -41,6 +82,10 @@ def _spectral(y, S, sr, n_fft, hop_length, win_length, window, center, pad_mode,
     else:
         if y is None:
             raise ValueError("Either y (audio) or S (spectrogram) must be provided")
+        fused = _spectral_from_audio(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, freq, power,
+                                     want, centroid, p, norm, roll_percent, amin)
+        if fused is not None:
+            return fused
         Sc = stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window,
                   center=center, pad_mode=pad_mode)
         S = torch.view_as_real(Sc)        # (…, F, T, 2): |X| is taken inside the kernel

@@ -315,3 +315,21 @@ def pcg64_uniform(seed, low, high, n):
                                        u64(st["inc"] & m), ctypes.c_double(low), ctypes.c_double(high),
                                        _i64(n), _p(out)))
     return out
+
+
+def spectral_from_audio(y, sr, hop, window, center=True, power=1.0, p=2.0, norm=True, roll_percent=0.85,
+                        amin=1e-10, want=("centroid", "bandwidth", "rolloff")):
+    """ap_spec2048_run_kernel (n_fft = 2048) on the CPU: {name: (B, T)}."""
+    y = np.ascontiguousarray(y, np.float32)
+    B, L = y.shape
+    T = n_frames(L, 2048, hop, center)
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(2048)
+    freq = np.linspace(0, sr / 2.0, 1025).astype(np.float32)
+    outs = {k: np.zeros((B, T), np.float32) for k in want}
+    g = lambda k: _p(outs[k]) if k in outs else None  # noqa: E731
+    f = ctypes.c_float
+    _check(lib().emu_spectral_audio_f32(_p(y), _i64(B), _i64(L), hop, _p(window), _p(tw), int(center), _i64(T),
+                                        _p(freq), f(power), f(p), int(norm), f(roll_percent), f(amin),
+                                        g("centroid"), g("bandwidth"), g("rolloff"), g("flatness")))
+    return outs

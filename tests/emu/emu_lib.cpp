@@ -401,6 +401,31 @@ int emu_resample_fft_f32(const float *x, int64_t B, int64_t Nx, int64_t num, con
                                       nullptr, ws, out);
 }
 
+int emu_spectral_audio_f32(const float *y, int64_t B, int64_t L, int hop, const float *window, const float *tw,
+                           int center, int64_t T, const float *freq, float power, float p, int norm,
+                           float roll_percent, float amin, float *centroid, float *bandwidth, float *rolloff,
+                           float *flatness) {
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, 2048, hop, window, tw, center, AP_PAD_CONSTANT, T);
+    if (rc != AP_OK) return rc;
+    ApSpecWaveParams W;
+    int grid = 0;
+    if (ap_prepare_spec_run(W, P, B, APM_WAVES, APW_X_COMPLEX, &grid) != AP_OK)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "spectral features from audio: shape not served");
+    if (grid > 1) grid = 1;
+    W.freq = freq;
+    W.centroid = centroid; W.bandwidth = bandwidth; W.rolloff = rolloff; W.flatness = flatness;
+    W.power = power; W.p = p; W.norm = norm; W.roll_percent = roll_percent; W.amin = amin;
+#define EMU_SPEC(PM, FL) do { if (W.hopj == 4 && p == 2.0f) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 4, FL, 0>(W); }); \
+                              else if (W.hopj == 4) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 4, FL, 1>(W); }); \
+                              else if (p == 2.0f) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 0, FL, 0>(W); }); \
+                              else emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 0, FL, 1>(W); }); } while (0)
+    if (flatness) { if (power == 2.0f) EMU_SPEC(2, 1); else if (power == 1.0f) EMU_SPEC(1, 1); else EMU_SPEC(0, 1); }
+    else { if (power == 2.0f) EMU_SPEC(2, 0); else if (power == 1.0f) EMU_SPEC(1, 0); else EMU_SPEC(0, 0); }
+#undef EMU_SPEC
+    return AP_OK;
+}
+
 int emu_cfft_split(int64_t N, int *N1, int *N2) { return ap_cfft_split(N, N1, N2); }
 
 int emu_pcg64_uniform_f32(unsigned long long st_hi, unsigned long long st_lo, unsigned long long inc_hi,

@@ -380,3 +380,26 @@ def test_emu_frames8_stft_kernels(n_fft, hop, L, B, center):
     got = eb.stft(y, n_fft, hop, win, center=center, pad_mode=0)
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("hop,L,B,center", [(512, 20000, 2, True), (300, 9000, 1, True), (512, 6000, 3, False)])
+def test_emu_spectral_statistics_from_audio(hop, L, B, center):
+    """ap_spec2048_run_kernel: transform + per-frame reductions in one kernel, against the oracle's
+    feature functions (reference features.py:57-442).  Tones + noise, one silent clip region."""
+    rng = np.random.default_rng(hop + L)
+    t = np.arange(L) / 22050.0
+    y = (0.5 * np.sin(2 * np.pi * 440.0 * t)[None] + 0.05 * rng.standard_normal((B, L))).astype(np.float32)
+    y[0, : L // 3] = 0.0                                        # digital silence: all-zero frames
+    win = ao.padded_window("hann", 2048, 2048)
+    kw = dict(sr=22050, n_fft=2048, hop_length=hop, center=center)
+    got = eb.spectral_from_audio(y, 22050, hop, win, center=center)
+    for b in range(B):
+        np.testing.assert_allclose(got["centroid"][b], ao.spectral_centroid(y[b], **kw)[0], rtol=2e-4, atol=1e-2)
+        np.testing.assert_allclose(got["bandwidth"][b], ao.spectral_bandwidth(y[b], **kw)[0], rtol=2e-4, atol=1e-2)
+        want = ao.spectral_rolloff(y[b], **kw)[0]
+        off = np.abs(got["rolloff"][b] - want) / (22050 / 2048)
+        assert off.max() <= 1.001 and (off > 0.5).mean() < 0.02         # at most the neighbouring bin, rarely
+    flat = eb.spectral_from_audio(y, 22050, hop, win, center=center, power=2.0, want=("flatness",))["flatness"]
+    for b in range(B):
+        np.testing.assert_allclose(flat[b], ao.spectral_flatness(y[b], n_fft=2048, hop_length=hop, center=center)[0],
+                                   rtol=2e-3, atol=1e-7)

@@ -238,3 +238,59 @@ def test_delta_errors_and_full_frontend(random_signal):
     want = np.concatenate([m, ao.delta(m), ao.delta(m, order=2)])
     assert feats.shape == (39, 44)
     np.testing.assert_allclose(host(feats), want, rtol=1e-3, atol=5e-3)
+
+
+# ------------------------------------------------------------------ fused statistics from audio (n_fft = 2048)
+@pytest.mark.parametrize("B,L,hop,center", [(300, 9000, 512, True), (5, 40001, 256, True), (3, 30000, 512, False),
+                                            (2, 2048, 2048, False)])
+def test_spectral_statistics_fused_from_audio_vs_two_kernel_route(B, L, hop, center):
+    """ap_spec2048_run_kernel (samples -> statistics, the spectrum never written) against the STFT kernel
+    + statistics kernel route (AP_SPEC_TWO_KERNELS) and the oracle; more frames than workgroups, a hop the
+    register rotation does not serve, no centring, a single frame."""
+    import os
+    rng = np.random.default_rng(B + L)
+    t = np.arange(L) / 22050.0
+    y = (0.3 * np.sin(2 * np.pi * (300.0 + 40.0 * np.arange(B))[:, None] * t[None]) +
+         0.05 * rng.standard_normal((B, L))).astype(np.float32)
+    y[0, : L // 2] = 0.0
+    kw = dict(sr=22050, n_fft=2048, hop_length=hop, center=center)
+    yd = dev(y)
+    fused = ap.spectral_features(yd, **kw)
+    flat = ap.spectral_flatness(yd, n_fft=2048, hop_length=hop, center=center)
+    bw3 = ap.spectral_bandwidth(yd, p=3.0, norm=False, **kw)
+    flat15 = ap.spectral_flatness(yd, n_fft=2048, hop_length=hop, center=center, power=1.5, amin=1e-6)
+    os.environ["AP_SPEC_TWO_KERNELS"] = "1"
+    try:
+        two = ap.spectral_features(yd, **kw)
+        flat2 = ap.spectral_flatness(yd, n_fft=2048, hop_length=hop, center=center)
+        bw32 = ap.spectral_bandwidth(yd, p=3.0, norm=False, **kw)
+        flat152 = ap.spectral_flatness(yd, n_fft=2048, hop_length=hop, center=center, power=1.5, amin=1e-6)
+    finally:
+        del os.environ["AP_SPEC_TWO_KERNELS"]
+    bin_hz = 22050 / 2048
+    for k in ("centroid", "bandwidth"):
+        assert fused[k].shape == two[k].shape
+        np.testing.assert_allclose(host(fused[k]), host(two[k]), rtol=2e-4, atol=2e-2)
+    off = np.abs(host(fused["rolloff"]) - host(two["rolloff"])) / bin_hz
+    assert off.max() <= 1.001 and (off > 0.5).mean() < 0.02
+    np.testing.assert_allclose(host(flat), host(flat2), rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(host(bw3), host(bw32), rtol=5e-4, atol=1e-1)
+    np.testing.assert_allclose(host(flat15), host(flat152), rtol=2e-3, atol=1e-7)
+    for b in sorted(set([0, B // 2, B - 1])):
+        np.testing.assert_allclose(host(fused["centroid"])[b], ao.spectral_centroid(y[b], **kw), rtol=2e-4, atol=2e-2)
+        np.testing.assert_allclose(host(fused["bandwidth"])[b], ao.spectral_bandwidth(y[b], **kw), rtol=2e-4, atol=2e-2)
+        np.testing.assert_allclose(host(flat)[b], ao.spectral_flatness(y[b], n_fft=2048, hop_length=hop, center=center),
+                                   rtol=2e-3, atol=1e-7)
+        offo = np.abs(host(fused["rolloff"])[b] - ao.spectral_rolloff(y[b], **kw)) / bin_hz
+        assert offo.max() <= 1.001 and (offo > 0.5).mean() < 0.02
+
+
+def test_spectral_statistics_fused_custom_freq_and_1d():
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(20000).astype(np.float32)
+    freq = (np.linspace(0, 1, 1025) ** 2 * 8000).astype(np.float32)
+    got = ap.spectral_centroid(dev(y), freq=freq)
+    assert got.shape == (1, 40)
+    np.testing.assert_allclose(host(got), ao.spectral_centroid(y, freq=freq), rtol=2e-4, atol=2e-2)
+    with pytest.raises(ValueError, match="freq must be 1D"):
+        ap.spectral_centroid(dev(y), freq=freq[:100])
