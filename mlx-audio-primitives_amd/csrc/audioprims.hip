@@ -834,6 +834,24 @@ int ap_frame_stats_f32(const float *y, int64_t B, int64_t L, int frame_length, i
         AP_FAIL(AP_ERR_INVALID, "frame statistics: n_frames mismatch (got %lld)", (long long)T);
     if (!rms && !zcr) return AP_OK;
     // frames per workgroup: the contiguous span (G - 1) hop + frame_length has to fit 64 KiB of LDS
+    // frame_length = m hop: every sample read once (block partial sums)
+    if (hop % 4 == 0 && frame_length % hop == 0 && frame_length / hop <= 16 && !std::getenv("AP_FRAME_STATS_SPAN")) {
+        ApFrameBlocksParams Q;
+        Q.y = y; Q.rms = rms; Q.zcr = zcr; Q.L = L; Q.T = T;
+        Q.frame_length = frame_length; Q.hop = hop; Q.pad = pad; Q.pad_mode = pad_mode;
+        Q.m = frame_length / hop;
+        int64_t G = APF_MAX_BLOCKS - Q.m + 1;
+        if (G > T) G = T;
+        // enough workgroups to fill the chip when the batch is small
+        while (G > 16 && ((T + G - 1) / G) * B < 1024) G = (G + 1) / 2;
+        Q.G = (int)G;
+        Q.tiles_per_clip = (T + G - 1) / G;
+        if (Q.tiles_per_clip * B <= kApMaxGrid) {
+            hipLaunchKernelGGL(ap_frame_stats_blocks_kernel, dim3((unsigned)(Q.tiles_per_clip * B)), dim3(AP_BLOCK), 0,
+                               (hipStream_t)stream, Q);
+            return ap_check_launch("ap_frame_stats_f32(blocks)");
+        }
+    }
     const int64_t budget = 16 * 1024;
     if (frame_length > 36 * 1024) AP_FAIL(AP_ERR_UNSUPPORTED, "frame_length %d does not fit LDS", frame_length);
     int64_t G = frame_length >= budget ? 1 : (budget - frame_length) / hop + 1;

@@ -156,6 +156,86 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_frame_stats_kernel(ApFrameStatsPa
     }
 }
 
+// The same for frame_length = m hop (the usual 2048 / 512, 1024 / 256, 400 / 160 ... shapes): every sample
+// is read ONCE.  A wave reduces one hop-sized block of the padded signal (16-byte loads, 4 samples per
+// lane and load) to three numbers - sum of squares, sign changes inside the block, sign change across its
+// left edge - and a frame is the sum of its m blocks (all inner edges, not its own left edge: the first
+// sample of a frame never counts, features.py:700-716).  A workgroup covers G frames = G + m - 1 blocks.
+struct ApFrameBlocksParams {
+    const float *y;            // (B, L)
+    float *rms, *zcr;          // (B, T), either may be NULL
+    int64_t L, T, tiles_per_clip;
+    int frame_length, hop, pad, pad_mode, m, G;
+};
+#define APF_MAX_BLOCKS 256
+
+AP_DEV int apf_cross(float a, float b) { return ((a >= 0.0f) != (b >= 0.0f)) ? 1 : 0; }
+
+__global__ void __launch_bounds__(AP_BLOCK) ap_frame_stats_blocks_kernel(ApFrameBlocksParams P) {
+    __shared__ float bss[APF_MAX_BLOCKS];
+    __shared__ int bzin[APF_MAX_BLOCKS], bzb[APF_MAX_BLOCKS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x / P.tiles_per_clip;
+    const int64_t t0 = (blockIdx.x - b * P.tiles_per_clip) * P.G;
+    const int Gt = (int)((P.T - t0) < P.G ? (P.T - t0) : P.G);
+    const int nb = Gt + P.m - 1;
+    const float *yb = P.y + b * P.L;
+    const int n4 = P.hop >> 2;                                // groups of 4 samples per block
+    for (int jj = wave; jj < nb; jj += AP_BLOCK / 64) {
+        const int64_t start = (t0 + jj) * (int64_t)P.hop - P.pad;        // unpadded index of the block's first sample
+        const bool interior = start >= 1 && start + P.hop <= P.L;
+        float ss = 0.0f;
+        int zin = 0, zb = 0;
+        float carry = interior ? yb[start - 1] : ap_load_padded(yb, P.L, start - 1, P.pad_mode);   // sample left of the block
+        for (int g0 = 0; g0 < n4; g0 += 64) {
+            const int gi = g0 + lane;
+            const bool act = gi < n4;
+            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f, x3 = 0.0f;
+            if (act) {
+                const int64_t s = start + 4 * (int64_t)gi;
+                if (interior) {
+                    const ap_rsp_f4u q = *reinterpret_cast<const ap_rsp_f4u *>(yb + s);
+                    x0 = q.x; x1 = q.y; x2 = q.z; x3 = q.w;
+                } else {
+                    x0 = ap_load_padded(yb, P.L, s, P.pad_mode);
+                    x1 = ap_load_padded(yb, P.L, s + 1, P.pad_mode);
+                    x2 = ap_load_padded(yb, P.L, s + 2, P.pad_mode);
+                    x3 = ap_load_padded(yb, P.L, s + 3, P.pad_mode);
+                }
+            }
+            // the sample before x0: the previous lane's x3, or what the previous trip (the block's left
+            // neighbour) left in `carry`
+            float left = __shfl_up(x3, 1, 64);
+            if (lane == 0) left = carry;
+            if (act) {
+                ss = fmaf(x0, x0, fmaf(x1, x1, fmaf(x2, x2, fmaf(x3, x3, ss))));
+                const int c0 = apf_cross(left, x0);
+                if (gi == 0) zb = c0; else zin += c0;
+                zin += apf_cross(x0, x1) + apf_cross(x1, x2) + apf_cross(x2, x3);
+            }
+            carry = __shfl(x3, 63, 64);                       // last sample of this trip (n4 > 64 only)
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            ss += __shfl_xor(ss, off, 64);
+            zin += __shfl_xor(zin, off, 64);
+            zb += __shfl_xor(zb, off, 64);
+        }
+        if (lane == 0) { bss[jj] = ss; bzin[jj] = zin; bzb[jj] = zb; }
+    }
+    __syncthreads();
+    for (int g = tid; g < Gt; g += AP_BLOCK) {
+        float ss = 0.0f;
+        int nc = 0;
+        for (int q = 0; q < P.m; ++q) {
+            ss += bss[g + q];
+            nc += bzin[g + q] + (q > 0 ? bzb[g + q] : 0);
+        }
+        if (P.rms) P.rms[b * P.T + t0 + g] = sqrtf(ss / (float)P.frame_length);
+        if (P.zcr) P.zcr[b * P.T + t0 + g] = (float)nc / (float)P.frame_length;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Pre-emphasis (framing.py:154-296): out[n] = y[n] - coef y[n-1]; out[0] = y[0] + zi, zi = the
 // caller's initial state or 2 y[0] - y[1]; zf = y[L-1].

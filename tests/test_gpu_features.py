@@ -294,3 +294,28 @@ def test_spectral_statistics_fused_custom_freq_and_1d():
     np.testing.assert_allclose(host(got), ao.spectral_centroid(y, freq=freq), rtol=2e-4, atol=2e-2)
     with pytest.raises(ValueError, match="freq must be 1D"):
         ap.spectral_centroid(dev(y), freq=freq[:100])
+
+
+@pytest.mark.parametrize("frame_length,hop,L,B,center,pad_mode", [
+    (2048, 512, 50001, 3, True, "edge"), (2048, 512, 50001, 3, True, "constant"), (1024, 256, 9000, 70, True, "edge"),
+    (400, 160, 16001, 2, True, "edge"), (400, 100, 3000, 2, False, "constant"), (2048, 2048, 30000, 2, True, "edge"),
+    (4096, 1024, 20000, 1, True, "constant"), (512, 128, 700, 5, True, "edge"), (64, 4, 500, 2, True, "edge"),
+])
+def test_rms_zcr_block_kernel_vs_span_kernel_and_oracle(frame_length, hop, L, B, center, pad_mode):
+    """frame_length = m hop: the block-partial kernel (every sample read once) against the LDS-span kernel
+    (AP_FRAME_STATS_SPAN) and the oracle; zero-crossing counts are exact."""
+    import os
+    rng = np.random.default_rng(frame_length + hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    y[0, 100:400] = 0.0                                   # exact zeros: (x >= 0) sign tests
+    kw = dict(frame_length=frame_length, hop_length=hop, center=center, pad_mode=pad_mode)
+    r, z = host(ap.rms(dev(y), **kw)), host(ap.zero_crossing_rate(dev(y), **kw))
+    os.environ["AP_FRAME_STATS_SPAN"] = "1"
+    try:
+        r2, z2 = host(ap.rms(dev(y), **kw)), host(ap.zero_crossing_rate(dev(y), **kw))
+    finally:
+        del os.environ["AP_FRAME_STATS_SPAN"]
+    np.testing.assert_allclose(r, r2, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(z, z2)
+    np.testing.assert_allclose(r, ao.rms(y, **kw), rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(z, ao.zero_crossing_rate(y, **kw))
