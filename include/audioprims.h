@@ -392,6 +392,12 @@ int ap_preemphasis_f32(const float *y /*dev (B,L)*/, int64_t B, int64_t L, float
 int ap_deemphasis_f32(const float *y /*dev (B,L)*/, int64_t B, int64_t L, float coef,
                       const float *zi /*dev (B) or NULL*/, float *out /*dev*/, float *zf /*dev (B) or NULL*/,
                       void *stream);
+/* The same with a workspace of ap_deemphasis_workspace_floats(B, L) floats: clips longer than 16 384
+ * samples are filtered in chunks on workgroups of their own (chunk end states first, then every chunk
+ * from the composed state it is entered with).  ws = NULL (or a short clip): one workgroup per clip. */
+int64_t ap_deemphasis_workspace_floats(int64_t B, int64_t L);
+int ap_deemphasis_ws_f32(const float *y /*dev*/, int64_t B, int64_t L, float coef, const float *zi /*dev (B) or NULL*/,
+                         float *out /*dev*/, float *zf /*dev (B) or NULL*/, float *ws /*dev*/, void *stream);
 
 /* delta(data, width, order, axis, mode) — mfcc.py:290-368 = scipy.signal.savgol_filter: FIR along the
  * middle axis of x viewed as (outer, n, inner); taps (width) in correlation order; mode AP_SG_*;

@@ -880,14 +880,39 @@ int ap_preemphasis_f32(const float *y, int64_t B, int64_t L, float coef, const f
     return ap_check_launch("ap_preemphasis_f32");
 }
 
+int64_t ap_deemphasis_workspace_floats(int64_t B, int64_t L) {
+    if (B <= 0 || L <= 0) return 0;
+    const int64_t tile = AP_BLOCK * APD_PER;
+    int64_t chunk = 4 * tile;                              // 16 384 samples
+    const int64_t n_chunks = (L + chunk - 1) / chunk;
+    return n_chunks > 1 ? B * n_chunks : 0;
+}
+
 int ap_deemphasis_f32(const float *y, int64_t B, int64_t L, float coef, const float *zi, float *out, float *zf,
                       void *stream) {
+    return ap_deemphasis_ws_f32(y, B, L, coef, zi, out, zf, nullptr, stream);
+}
+
+int ap_deemphasis_ws_f32(const float *y, int64_t B, int64_t L, float coef, const float *zi, float *out, float *zf,
+                         float *ws, void *stream) {
     if (!y || !out) AP_FAIL(AP_ERR_INVALID, "deemphasis: NULL buffer");
     if (!(coef >= 0.0f && coef <= 1.0f)) AP_FAIL(AP_ERR_INVALID, "coef must be in [0, 1], got %g", (double)coef);
     if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "deemphasis: signal must be non-empty");
+    const int64_t chunk = 4 * (int64_t)AP_BLOCK * APD_PER;
+    const int64_t n_chunks = (L + chunk - 1) / chunk;
+    if (ws && n_chunks > 1 && B * n_chunks <= kApMaxGrid) {
+        // chunked: end states of all chunks, then every chunk from its composed entering state
+        hipLaunchKernelGGL(ap_deemphasis_kernel<1>, dim3((unsigned)(B * n_chunks)), dim3(AP_BLOCK), 0, (hipStream_t)stream,
+                           y, L, coef, zi, zi ? 0 : 1, out, zf, chunk, (int)n_chunks, ws);
+        int rc = ap_check_launch("ap_deemphasis_f32(carries)");
+        if (rc != AP_OK) return rc;
+        hipLaunchKernelGGL(ap_deemphasis_kernel<2>, dim3((unsigned)(B * n_chunks)), dim3(AP_BLOCK), 0, (hipStream_t)stream,
+                           y, L, coef, zi, zi ? 0 : 1, out, zf, chunk, (int)n_chunks, ws);
+        return ap_check_launch("ap_deemphasis_f32(chunks)");
+    }
     if (B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "deemphasis: grid too large");
-    hipLaunchKernelGGL(ap_deemphasis_kernel, dim3((unsigned)B), dim3(AP_BLOCK), 0, (hipStream_t)stream, y, L, coef, zi,
-                       zi ? 0 : 1, out, zf);
+    hipLaunchKernelGGL(ap_deemphasis_kernel<0>, dim3((unsigned)B), dim3(AP_BLOCK), 0, (hipStream_t)stream, y, L, coef, zi,
+                       zi ? 0 : 1, out, zf, L, 1, nullptr);
     return ap_check_launch("ap_deemphasis_f32");
 }
 

@@ -90,8 +90,16 @@ def _emphasis(fn_name, y, coef, zi, return_zf):
     out = torch.empty_like(y)
     zf = torch.empty((B, 1), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
-        _x.check(getattr(_x.dlib(dev), fn_name)(_x.ptr(y), B, L, float(coef), None if z is None else _x.ptr(z),
-                                                 _x.ptr(out), _x.ptr(zf), _x.stream_ptr(dev)))
+        if fn_name == "ap_deemphasis_f32":
+            # long clips: chunk end states in a small workspace, every chunk on a workgroup of its own
+            n_ws = int(_x.lib().ap_deemphasis_workspace_floats(B, L))
+            ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
+            _x.check(_x.dlib(dev).ap_deemphasis_ws_f32(_x.ptr(y), B, L, float(coef), None if z is None else _x.ptr(z),
+                                                       _x.ptr(out), _x.ptr(zf), _x.ptr(ws) if n_ws else None,
+                                                       _x.stream_ptr(dev)))
+        else:
+            _x.check(getattr(_x.dlib(dev), fn_name)(_x.ptr(y), B, L, float(coef), None if z is None else _x.ptr(z),
+                                                     _x.ptr(out), _x.ptr(zf), _x.stream_ptr(dev)))
     if one_d:
         out, zf = out[0], zf[0]
     return (out, zf) if return_zf else out

@@ -202,6 +202,21 @@ def test_emphasis_with_given_state_and_errors(batch_signals):
         ap.deemphasis(dev(y), coef=-0.1)
 
 
+@pytest.mark.parametrize("coef", [0.97, 0.999, 1.0])
+@pytest.mark.parametrize("zi", [None, 0.3])
+def test_deemphasis_chunked_long_clips(coef, zi):
+    """Clips longer than 16 384 samples run as chunks on their own workgroups (end states, then the
+    chunks from their composed entering states): 7 chunks, the last one ragged; a slowly decaying and a
+    non-decaying (coef = 1) recursion carry state across every chunk border."""
+    rng = np.random.default_rng(17)
+    y = (rng.standard_normal((3, 100001)) * 0.1).astype(np.float32)
+    d, zf = ap.deemphasis(dev(y), coef=coef, zi=zi, return_zf=True)
+    dw, zfw = ao.deemphasis(y, coef=coef, zi=zi, return_zf=True)
+    scale = float(np.abs(dw).max())
+    np.testing.assert_allclose(host(d), dw, rtol=1e-4, atol=2e-5 * max(1.0, scale))
+    np.testing.assert_allclose(host(zf), zfw, rtol=1e-4, atol=2e-5 * max(1.0, scale))
+
+
 # ------------------------------------------------------------------ delta
 @pytest.mark.parametrize("width,order", [(9, 1), (9, 2), (5, 1), (3, 1), (7, 2)])
 def test_delta_matches_savgol(random_signal, width, order):
