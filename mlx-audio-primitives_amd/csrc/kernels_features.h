@@ -54,14 +54,33 @@ __global__ void __launch_bounds__(APF_TX * APF_TY) ap_spectral_stats_kernel(ApSp
     const int64_t k0 = ty * per, k1 = k0 + per < P.F ? k0 + per : P.F;
 
     float s0 = 0.0f, s1 = 0.0f, sl = 0.0f, sa = 0.0f;
+    const bool want_flat = P.flatness != nullptr;            // 1025 logs per frame only when they are wanted
     if (live) {
-        for (int64_t k = k0; k < k1; ++k) {
+        int64_t k = k0;
+        for (; k + 4 <= k1; k += 4) {                        // four rows in flight per thread
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = apf_load_mag(P, Sb, k + u, t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0 += v[u];
+                s1 = fmaf(P.freq[k + u], v[u], s1);
+                if (want_flat) {
+                    const float c = fmaxf(v[u], P.amin);
+                    sl += logf(c);
+                    sa += c;
+                }
+            }
+        }
+        for (; k < k1; ++k) {
             const float v = apf_load_mag(P, Sb, k, t);
             s0 += v;
             s1 = fmaf(P.freq[k], v, s1);
-            const float c = fmaxf(v, P.amin);
-            sl += logf(c);
-            sa += c;
+            if (want_flat) {
+                const float c = fmaxf(v, P.amin);
+                sl += logf(c);
+                sa += c;
+            }
         }
     }
     red[0][ty][tx] = s0; red[1][ty][tx] = s1; red[2][ty][tx] = sl; red[3][ty][tx] = sa;
@@ -84,7 +103,22 @@ __global__ void __launch_bounds__(APF_TX * APF_TY) ap_spectral_stats_kernel(ApSp
     float dev = 0.0f, run = before;
     int64_t found = -1;
     if (live && (P.bandwidth || mine)) {
-        for (int64_t k = k0; k < k1; ++k) {
+        int64_t k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = apf_load_mag(P, Sb, k + u, t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (P.bandwidth) {
+                    const float d = fabsf(P.freq[k + u] - cen);
+                    dev = fmaf(v[u], P.p == 2.0f ? d * d : powf(d, P.p), dev);
+                }
+                run += v[u];
+                if (mine && found < 0 && run >= thr) found = k + u;
+            }
+        }
+        for (; k < k1; ++k) {
             const float v = apf_load_mag(P, Sb, k, t);
             if (P.bandwidth) {
                 const float d = fabsf(P.freq[k] - cen);
