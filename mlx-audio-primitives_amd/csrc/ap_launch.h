@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdio>
 
+#include <cstdlib>
 #include "../../include/audioprims.h"
 #include "ap_common.h"
 #include "ap_wave_params.h"
@@ -554,7 +555,10 @@ static inline int ap_prepare_cfft_leg(ApCfftParams &C, int n, int64_t n_frames, 
     const int fstride = n + 1;
     const int64_t per_frame = (int64_t)2 * fstride * (int64_t)sizeof(ap_float2);
     if (per_frame > AP_LDS_MAX) AP_FAIL(AP_ERR_UNSUPPORTED, "cfft: length %d does not fit LDS", n);
-    int G = (int)(AP_LDS_TILE_BUDGET / per_frame);
+    // 32 KB of LDS per workgroup = 4-5 workgroups per CU: the legs are latency-bound between their passes
+    // (resample 256 x 220 500 -> 160 000: 3.75 ms at 64 KB, 2.50 at 32 KB, 2.86 at 16 KB; AP_CFFT_BUDGET overrides)
+    static const int budget = std::getenv("AP_CFFT_BUDGET") ? std::atoi(std::getenv("AP_CFFT_BUDGET")) : 32 * 1024;
+    int G = (int)(budget / per_frame);
     if (G < 1) G = 1;
     if (G > AP_MAX_G) G = AP_MAX_G;
     if ((int64_t)G > n_frames) G = (int)n_frames;
