@@ -448,6 +448,21 @@ static int ap_launch_resample_poly(const float *x, int64_t B, int64_t L, int up,
             return ap_check_launch("ap_resample_poly_f32(decim)");
         }
     }
+    if (up > 1 && !std::getenv("AP_RESAMPLE_NAIVE")) {     // polyphase table + input span in LDS
+        const int K = (n_taps + up - 1) / up, KS = K | 1;
+        const int64_t per_block = (int64_t)AP_BLOCK * AP_RSPL_R;
+        const int64_t span = (per_block * down) / up + K + 4;
+        const int64_t lds = ((int64_t)up * KS + span) * (int64_t)sizeof(float);
+        const int64_t bprl = (n_out + per_block - 1) / per_block;
+        if (lds <= 64 * 1024 && bprl * B <= kApMaxGrid) {
+            rc = ap_allow_lds(ap_resample_poly_lds_kernel, (int)lds);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(ap_resample_poly_lds_kernel, dim3((unsigned)(bprl * B)), dim3(AP_BLOCK), (size_t)lds,
+                               (hipStream_t)stream, x, L, up, down, taps, n_taps, n_pre_remove, n_out, bprl, K, KS,
+                               (int)span, out);
+            return ap_check_launch("ap_resample_poly_f32(lds)");
+        }
+    }
     hipLaunchKernelGGL(ap_resample_poly_kernel, dim3((unsigned)(bpr * B)), dim3(AP_BLOCK), 0,
                        (hipStream_t)stream, x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
     return ap_check_launch("ap_resample_poly_f32");

@@ -262,6 +262,54 @@ ap_resample_poly_kernel(const float *x, int64_t L, int up, int down, const float
     out[b * n_out + o] = acc;
 }
 
+// The same for up > 1 (44.1 kHz <-> 48 kHz: 160 / 147) with the filter and the input span in LDS: a
+// workgroup owns 256 R consecutive outputs, stages the input samples they touch once (zeros outside the
+// clip = SciPy's zero padding) and the polyphase table hp[ph][k] = taps[ph + k up] (zero past the filter;
+// row stride odd); output o with t = (o + n_pre_remove) down, ph = t mod up, i = t div up is
+// sum_k hp[ph][k] x[i - k], accumulated from the largest k down = increasing input index, the product
+// rounded before the sum: the order and roundings of SciPy's loop, so still bit-exact.
+#define AP_RSPL_R 4
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_resample_poly_lds_kernel(const float *x, int64_t L, int up, int down, const float *taps, int n_taps,
+                            int n_pre_remove, int64_t n_out, int64_t blocks_per_row, int K, int KS, int span,
+                            float *out) {
+#ifndef AP_HOST_EMU
+#pragma clang fp contract(off)   // SciPy's C loop rounds the product, then the sum: no FMA
+#endif
+    float *hp = reinterpret_cast<float *>(ap_smem);          // [up][KS]
+    float *xs = hp + (size_t)up * KS;                        // [span]
+    const int tid = threadIdx.x;
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / blocks_per_row;
+    const int64_t o0 = (bid - b * blocks_per_row) * (int64_t)(AP_BLOCK * AP_RSPL_R);
+    const float *xb = x + b * L;
+    // first input sample any output of the block touches: i(o0) - (K - 1)
+    const int64_t lo = ((o0 + n_pre_remove) * (int64_t)down) / up - (K - 1);
+    for (int i = tid; i < up * KS; i += AP_BLOCK) {
+        const int ph = i / KS, k = i - ph * KS;
+        const int64_t j = ph + (int64_t)k * up;
+        hp[i] = (k < K && j < n_taps) ? taps[j] : 0.0f;
+    }
+    for (int i = tid; i < span; i += AP_BLOCK) {
+        const int64_t n = lo + i;
+        xs[i] = (n >= 0 && n < L) ? xb[n] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < AP_RSPL_R; ++r) {
+        const int64_t o = o0 + tid + (int64_t)AP_BLOCK * r;
+        if (o >= n_out) break;
+        const int64_t t = (o + n_pre_remove) * (int64_t)down;
+        const int64_t iq = t / up;
+        const int ph = (int)(t - iq * up);
+        const float *h = hp + ph * KS;
+        const float *xr = xs + (int)(iq - lo);               // x[i]; x[i - k] = xr[-k]
+        float acc = 0.0f;
+        for (int k = K - 1; k >= 0; --k) acc = acc + h[k] * xr[-k];
+        out[b * n_out + o] = acc;
+    }
+}
+
 // Decimating case (up == 1, e.g. 48 kHz -> 16 kHz) of the same filter, LDS-tiled and register
 // blocked: a workgroup stages the contiguous input span of 256*R outputs once (coalesced,
 // zeros outside the clip = SciPy's zero padding) and every thread slides over the span

@@ -271,6 +271,19 @@ int emu_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down
         });
         return AP_OK;
     }
+    if (up > 1) {
+        const int K = (n_taps + up - 1) / up, KS = K | 1;
+        const int64_t per_block = (int64_t)AP_BLOCK * AP_RSPL_R;
+        const int64_t span = (per_block * down) / up + K + 4;
+        const int64_t lds = ((int64_t)up * KS + span) * (int64_t)sizeof(float);
+        const int64_t bprl = (n_out + per_block - 1) / per_block;
+        if (lds <= 64 * 1024) {
+            emu_launch((unsigned)(bprl * B), AP_BLOCK, [&] {
+                ap_resample_poly_lds_kernel(x, L, up, down, taps, n_taps, n_pre_remove, n_out, bprl, K, KS, (int)span, out);
+            });
+            return AP_OK;
+        }
+    }
     emu_launch((unsigned)(bpr * B), AP_BLOCK, [&] {
         ap_resample_poly_kernel(x, L, up, down, taps, n_taps, n_pre_remove, n_out, bpr, out);
     });

@@ -250,6 +250,11 @@ def test_emu_resample_poly_bit_exact_vs_scipy():
         xx = rng.standard_normal((2, L)).astype(np.float32)
         np.testing.assert_array_equal(eb.resample_poly(xx, 1, down),
                                       scipy.signal.resample_poly(xx, 1, down, axis=-1).astype(np.float32))
+    # LDS-tiled interpolating cases (up > 1): several workgroups, ragged ends, large and tiny ratios
+    for up, down, L in ((160, 147, 5000), (2, 1, 3001), (3, 2, 2500), (4, 3, 1025), (2, 9, 9001), (7, 5, 60), (441, 160, 400)):
+        xx = rng.standard_normal((2, L)).astype(np.float32)
+        np.testing.assert_array_equal(eb.resample_poly(xx, up, down),
+                                      scipy.signal.resample_poly(xx, up, down, axis=-1).astype(np.float32))
     x = np.random.default_rng(0).standard_normal((2, 1000)).astype(np.float32)
     np.testing.assert_array_equal(eb.resample_linear(x, 733), ao.resample(x, 1000, 733, res_type="linear"))
     np.testing.assert_allclose(eb.resample_linear(x, 1500, scale=1.5),
