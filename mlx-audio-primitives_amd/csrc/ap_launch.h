@@ -381,6 +381,76 @@ static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bo
     return AP_OK;
 }
 
+// inverse eight-frames-per-wave kernel (kernels_frames8.h, ap_irfft8_wave_kernel): frames from the spectrum
+template <class W8>
+static inline int ap_prepare_irfft8(W8 &W, const ApIrfftParams &P, int64_t B, int R, int bs, int n_waves, int *grid) {
+    if (P.plan.n != 16 * R) return 1;
+    if (P.T > (1 << 19)) return 1;                          // a clip's spectrum rows < 2 GiB (32-bit offsets)
+    W.S = reinterpret_cast<const ap_float2 *>(P.S);
+    W.tw = P.tw;
+    W.frames = P.frames;
+    W.T = P.T;
+    W.n_clips = B;
+    W.groups_per_clip = (P.T + 7) / 8;
+    W.n_groups = W.groups_per_clip * B;
+    int off = 0;
+    W.off_t = off; off += 8 * bs * (int)sizeof(ap_float2);
+    W.off_s = off; off += 8 * bs * (int)sizeof(ap_float2);
+    W.lds_bytes = off;
+    int64_t g = (W.n_groups + (int64_t)n_waves * 2 - 1) / ((int64_t)n_waves * 2);
+    if (g > 1024) g = 1024;                                  // 8 KB of LDS, 8 waves: up to four workgroups' worth of work per CU
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
+// fused ISTFT of the eight-frames-per-wave family (kernels_frames8.h, ap_istft8_wave_kernel): n_fft 512 / 400 /
+// 256 with n_fft / 8 <= hop <= n_fft.  `ap_istft8_lds_bytes` < 0: the shape is not served.
+static inline int ap_istft8_block_stride(int n_fft) {       // ApqGeom<R>::BS
+    const int R = n_fft / 16;
+    return R + (R % 2 == 0 ? 1 : 0);
+}
+static inline int ap_istft8_lds_bytes(int64_t T, int n_fft, int hop, int n_waves) {
+    if (n_fft != 512 && n_fft != 400 && n_fft != 256) return -1;
+    if (hop <= 0 || hop > n_fft || 8 * hop < n_fft) return -1;
+    if (T <= 0 || T > (1 << 19)) return -1;
+    const int span = 7 * hop + n_fft;
+    const int64_t bytes = 2 * 8 * ap_istft8_block_stride(n_fft) * 8 + n_fft * 4 + ap_align16(hop * 4) + (int64_t)n_waves * span * 4;
+    return bytes <= AP_LDS_MAX ? (int)bytes : -1;
+}
+template <class W8>
+static inline int ap_prepare_istft8(W8 &W, const float *S, const float *tw, int64_t B, int64_t T, int n_fft,
+                                    const float *window, int hop, int64_t out_offset, int64_t out_len, float *y,
+                                    int n_waves, int *grid) {
+    if (ap_istft8_lds_bytes(T, n_fft, hop, n_waves) < 0 || out_offset < 0) return 1;
+    W.S = reinterpret_cast<const ap_float2 *>(S);
+    W.tw = reinterpret_cast<const ap_float2 *>(tw);
+    W.window = window;
+    W.y = y;
+    W.T = T;
+    W.n_clips = B;
+    W.groups_per_clip = (T + 7) / 8;
+    W.n_groups = W.groups_per_clip * B;
+    W.out_offset = out_offset;
+    W.out_len = out_len;
+    W.hop = hop;
+    W.span = 7 * hop + n_fft;
+    const int bs = ap_istft8_block_stride(n_fft);
+    int off = 0;
+    W.off_t = off; off += 8 * bs * 8;
+    W.off_s = off; off += 8 * bs * 8;
+    W.off_w2 = off; off += n_fft * 4;
+    W.off_wss = off; off += ap_align16(hop * 4);
+    W.off_acc = off; off += n_waves * W.span * 4;
+    W.lds_bytes = off;
+    // stretches of >= 4 groups: every stretch that starts inside a clip pays one warm-up group
+    int64_t g = (W.n_groups + (int64_t)n_waves * 4 - 1) / ((int64_t)n_waves * 4);
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // n_fft = 1024 wave-per-frame mel kernel (kernels_wave512.h): constant padding, plan with parts,
 // at most 128 filters (two rows per lane).  Returns 1 when it does not apply.
 struct ApMelWave512Params;

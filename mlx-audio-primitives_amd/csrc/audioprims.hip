@@ -170,6 +170,19 @@ static int ap_launch_spec_run(const ApSpecWaveParams &W, int grid, void *stream)
                 : ap_launch_spec_run4<PMODE, 0, FLAT, 0>(W, grid, stream);
 }
 
+template <int R>
+static int ap_launch_irfft8(const ApIrfftParams &P, int64_t B, void *stream, bool *handled) {
+    ApIrfft8Params W;
+    int grid = 0;
+    *handled = false;
+    if (ap_prepare_irfft8(W, P, B, R, ApqGeom<R>::BS, APQ_WAVES, &grid) != AP_OK) return AP_OK;
+    int rc = ap_allow_lds(ap_irfft8_wave_kernel<R>, W.lds_bytes);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL(ap_irfft8_wave_kernel<R>, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+    *handled = true;
+    return ap_check_launch("ap_irfft_frames_f32(frames8)");
+}
+
 extern "C" {
 
 int ap_version(void) { return 100; }
@@ -379,6 +392,12 @@ int ap_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const f
             return ap_check_launch("ap_irfft_frames_f32(wave)");
         }
     }
+    if ((n_fft == 512 || n_fft == 400 || n_fft == 256) && !std::getenv("AP_IRFFT8_GENERIC")) {
+        bool handled = false;
+        rc = n_fft == 512 ? ap_launch_irfft8<32>(P, B, stream, &handled)
+             : n_fft == 400 ? ap_launch_irfft8<25>(P, B, stream, &handled) : ap_launch_irfft8<16>(P, B, stream, &handled);
+        if (rc != AP_OK || handled) return rc;
+    }
     rc = ap_allow_lds(ap_irfft_generic_kernel, P.tile.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(ap_irfft_generic_kernel, dim3((unsigned)(P.tiles_per_clip * B)),
@@ -390,6 +409,7 @@ int64_t ap_istft_workspace_floats(int64_t B, int64_t T, int n_fft, int hop, int6
     if (B <= 0 || T <= 0 || n_fft <= 0) return 0;
     if (ap_istft_fused_shape(B, T, n_fft, hop, out_offset)) return 0;
     if (ap_istft1024_fused_shape(B, T, n_fft, hop, out_offset)) return 0;
+    if (out_offset >= 0 && ap_istft8_lds_bytes(T, n_fft, hop, APQ_WAVES) >= 0 && !std::getenv("AP_ISTFT8_UNFUSED")) return 0;
     return B * T * (int64_t)n_fft;
 }
 
@@ -421,6 +441,18 @@ int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const
             hipLaunchKernelGGL(ap_istft1024_wave_kernel, dim3(grid), dim3(64 * APHS_WAVES), W.lds_bytes,
                                (hipStream_t)stream, W);
             return ap_check_launch("ap_istft_f32(fused 1024)");
+        }
+    }
+    if (S && tw && window && out && out_len > 0 && B > 0 && !std::getenv("AP_ISTFT8_UNFUSED")) {
+        ApIstft8Params W;
+        int grid = 0;
+        if (ap_prepare_istft8(W, S, tw, B, T, n_fft, window, hop, out_offset, out_len, out, APQ_WAVES, &grid) == AP_OK) {
+            auto kern = n_fft == 512 ? ap_istft8_wave_kernel<32> : n_fft == 400 ? ap_istft8_wave_kernel<25>
+                                                                                 : ap_istft8_wave_kernel<16>;
+            int rc0 = ap_allow_lds(kern, W.lds_bytes);
+            if (rc0 != AP_OK) return rc0;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+            return ap_check_launch("ap_istft_f32(fused frames8)");
         }
     }
     if (!frames_ws) AP_FAIL(AP_ERR_INVALID, "istft: NULL workspace");

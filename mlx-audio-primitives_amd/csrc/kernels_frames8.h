@@ -438,3 +438,266 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_stft8_wave_kernel(ApFram
         if (Ln.q == 0) ap_outbuf_store2(ob, lb, 8u * (unsigned)(NC * Ti + t0), ap_mk(v[0].x - v[0].y, 0.0f));   // bin 8R
     });
 }
+
+// ---------------------------------------------------------------------------------------------
+// Inverse: frames (B, T, 16 R) float32 from the spectrum (B, 8R + 1, T) complex64 (mx.fft.irfft, stft.py:295)
+// ---------------------------------------------------------------------------------------------
+// The forward machinery is reused as it stands: the spectrum is LOADED in the transform's input layout
+// (lane (g, q), register r = bin q + 8 r of frame g), merged with its Hermitian mirror into the packed
+// half-length spectrum - conjugated - and sent through apq_transform; lane q then holds
+// conj(NC z[m]) for the R contiguous m = k1 + R k2(q), i.e. the 2 R contiguous samples
+// x[2m] = Re / NC, x[2m + 1] = -Im / NC of the frame.
+//   conj Z[k] = (Xm + conj X) / 2 - (-i) (W_16R^k / 2) (Xm - conj X),  Xm = X[8R - k]
+// (the mirror of bin q + 8 r is bin (8 - q) + 8 (R - 1 - r): lane 8 - q of the frame, fetched with one
+// ds_bpermute per component; lane q = 0 mirrors onto itself, register R - r, and onto the Nyquist bin for
+// r = 0; the imaginary parts of bins 0 and 8R are ignored like numpy / mlx irfft do).
+struct ApIrfft8Params {
+    const ap_float2 *S;        // (B, 8R + 1, T)
+    const ap_float2 *tw;       // (16 R)
+    float *frames;             // (B, T, 16 R)
+    int64_t T, n_clips, groups_per_clip, n_groups;
+    int off_t, off_s, lds_bytes;
+};
+
+// spectrum rows of frame t0 + g (lane part lb of the address; lanes of frames past T hold an out-of-range
+// one and read zeros) -> conj(NC z[m]) of the lane's R contiguous m
+template <int R>
+AP_DEV void apq_inverse_frame(ApOutBuf sb, unsigned lb, int Ti, int t0, const ap_float2 *Smrow, const ap_float2 *Trow,
+                              const ApqLane &Ln, int msrc, ap_float2 (&v)[R]) {
+    const int q = Ln.q;
+    const ap_float2 half = ap_mk(0.5f, 0.5f);
+    ap_float2 X[R + 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) X[r] = ap_outbuf_load2(sb, lb, 8u * (unsigned)(8 * r * Ti + t0));
+    // row 8R, the Nyquist bin: lane q = 0 only (the uniform part of an address is not range-checked, so the
+    // other lanes must not reach past their clip's rows)
+    X[R] = ap_outbuf_load2(sb, q == 0 ? lb : 0xF0000000u, 8u * (unsigned)(8 * R * Ti + t0));
+    if (q == 0) { X[0].y = 0.0f; X[R].y = 0.0f; }
+    ap_float2 sw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sw[r] = Smrow[r];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        // what this lane offers to its mirror lane: register R - 1 - r (q = 0: its own register R - r)
+        // (both candidates are pinned as values first: left alone, the compiler turns the select of two array
+        // elements into one dynamically indexed element and the whole array moves to scratch memory)
+        ap_float2 g0 = X[R - r], g1 = X[R - 1 - r];
+        AP_PIN(g0);
+        AP_PIN(g1);
+        const ap_float2 give = q == 0 ? g0 : g1;
+        const ap_float2 xm = ap_mk(apq_lane_read(give.x, msrc), apq_lane_read(give.y, msrc));
+        const ap_float2 a = ap_add_conj(xm, X[r]), d = ap_sub_conj(xm, X[r]);
+        v[r] = ap_fma_sub_mi(a, half, ap_mul_fw(d, sw[r]));
+    }
+    apq_transform<R>(v, Trow, Ln);
+}
+
+// the two LDS tables of the inverse kernels: Tt as in the forward kernels, Sm[q][r] = W_16R^(q + 8 r) / 2
+template <int R>
+AP_DEV void apq_fill_inverse_tables(ap_float2 *Tt, ap_float2 *Sm, const ap_float2 *tw, int tid, int nt) {
+    constexpr int BS = ApqGeom<R>::BS;
+    apq_fill_tables<R>(Tt, Sm, tw, tid, nt);                 // (Sm is overwritten just below)
+    AP_LDS_BARRIER();
+    for (int i = tid; i < 8 * R; i += nt) {
+        const int qq = i / R, r = i - qq * R;
+        Sm[qq * BS + r] = ap_scale(tw[qq + 8 * r], 0.5f);
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_irfft8_wave_kernel(ApIrfft8Params P) {
+    typedef ApqGeom<R> G;
+    constexpr int NC = G::NC, BS = G::BS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *Tt = reinterpret_cast<ap_float2 *>(ap_smem + P.off_t);           // [8][BS]
+    ap_float2 *Sm = reinterpret_cast<ap_float2 *>(ap_smem + P.off_s);           // [8][BS]
+    apq_fill_inverse_tables<R>(Tt, Sm, P.tw, tid, 64 * APQ_WAVES);
+    const ApqLane Ln = apq_lane_make(lane, P.tw, R);
+    const int g = Ln.g, q = Ln.q;
+    AP_LDS_BARRIER();
+    const int Ti = (int)P.T;
+    const int msrc = (lane & ~7) | ((8 - q) & 7);                               // lane holding the mirror bins
+    const float sc = 1.0f / (float)NC;
+    const ap_float2 scv = ap_mk(sc, -sc);                                       // conj and 1 / NC in one multiply
+    const int64_t clip_bytes = (int64_t)(NC + 1) * P.T * 8;
+    const unsigned lane_bytes = 8u * ((unsigned)q * (unsigned)Ti + (unsigned)g);
+
+    const int64_t worker = (int64_t)blockIdx.x * APQ_WAVES + wave;
+    const int64_t n_workers = (int64_t)gridDim.x * APQ_WAVES;
+    const int64_t grp_lo = P.n_groups * worker / n_workers, grp_hi = P.n_groups * (worker + 1) / n_workers;
+    for (int64_t grp = grp_lo; grp < grp_hi; ++grp) {
+        const int64_t b = grp / P.groups_per_clip;
+        const int t0 = (int)(grp - b * P.groups_per_clip) * 8;
+        const bool live = t0 + g < Ti;
+        const ApOutBuf sb = ap_outbuf_make(const_cast<char *>(reinterpret_cast<const char *>(P.S)) + b * clip_bytes, clip_bytes);
+        ap_float2 v[R];
+        apq_inverse_frame<R>(sb, live ? lane_bytes : 0xF0000000u, Ti, t0, Sm + q * BS, Tt + q * BS, Ln, msrc, v);
+        if (live) {
+            float *fr = P.frames + ((b * P.T + t0 + g) * (int64_t)(2 * NC)) + 2 * R * Ln.k2;
+#pragma unroll
+            for (int k1 = 0; k1 < R; ++k1) reinterpret_cast<ap_float2 *>(fr)[k1] = ap_mul2(v[k1], scv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ISTFT in one kernel (stft.py:292-338: irfft -> overlap-add -> window-sum-squares normalisation -> trim):
+// the frames never reach HBM.  A wave walks a contiguous stretch of 8-frame groups; its windowed samples go
+// into the wave's LDS accumulator (span 7 hop + n_fft samples from the group's first
+// sample; the first n_fft - hop of them are what the previous group left), the 8 hop samples the group
+// completes are normalised (window-sum-squares of the frames that exist: a table for interior positions, a
+// sum over the <= n_fft / hop covering frames at the clip's ends) and stored with the centre trim folded
+// in; the tail becomes the next group's carry.  The last group of a clip emits its tail as well and
+// zero-fills what is left of the output row.  A stretch that starts inside a clip first runs the
+// preceding group with its stores disabled to rebuild the carry (n_fft - hop <= 8 hop).
+// ---------------------------------------------------------------------------------------------
+struct ApIstft8Params {
+    const ap_float2 *S;        // (B, 8R + 1, T)
+    const ap_float2 *tw;       // (16 R)
+    const float *window;       // (16 R)
+    float *y;                  // (B, out_len)
+    int64_t T, n_clips, groups_per_clip, n_groups, out_offset, out_len;
+    int hop, span;             // span = 7 hop + n_fft
+    int off_t, off_s, off_w2, off_wss, off_acc, lds_bytes;
+};
+
+
+template <int R>
+__global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_istft8_wave_kernel(ApIstft8Params P) {
+    typedef ApqGeom<R> G;
+    constexpr int NC = G::NC, BS = G::BS, N = 2 * NC;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *Tt = reinterpret_cast<ap_float2 *>(ap_smem + P.off_t);
+    ap_float2 *Sm = reinterpret_cast<ap_float2 *>(ap_smem + P.off_s);
+    float *W2 = reinterpret_cast<float *>(ap_smem + P.off_w2);                  // [N] window^2
+    float *WSS = reinterpret_cast<float *>(ap_smem + P.off_wss);                // [hop] sum over all covering frames
+    float *acc = reinterpret_cast<float *>(ap_smem + P.off_acc) + wave * P.span;
+    const int hop = P.hop, span = P.span;
+    {
+        const int nt = 64 * APQ_WAVES;
+        apq_fill_inverse_tables<R>(Tt, Sm, P.tw, tid, nt);
+        for (int i = tid; i < N; i += nt) { const float w = P.window[i]; W2[i] = w * w; }
+        for (int i = tid; i < hop; i += nt) {
+            float s = 0.0f;
+            // frames in increasing order = decreasing window index, like ap_overlap_add_kernel's loop
+            int s0 = i;
+            while (s0 + hop < N) s0 += hop;
+            for (int j = s0; j >= 0; j -= hop) { const float w = P.window[j]; s += w * w; }
+            WSS[i] = s;
+        }
+        for (int i = tid; i < APQ_WAVES * span; i += nt) reinterpret_cast<float *>(ap_smem + P.off_acc)[i] = 0.0f;
+    }
+    const ApqLane Ln = apq_lane_make(lane, P.tw, R);
+    const int g = Ln.g, q = Ln.q;
+    const int Ti = (int)P.T;
+    const int msrc = (lane & ~7) | ((8 - q) & 7);
+    const float sc = 1.0f / (float)NC;
+    // the window pairs of this lane's samples with the 1 / NC and the conjugation folded in
+    ap_float2 wv[R];
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) {
+        const ap_float2 w = reinterpret_cast<const ap_float2 *>(P.window)[R * Ln.k2 + k1];
+        wv[k1] = ap_mk(w.x * sc, -w.y * sc);
+    }
+    AP_LDS_BARRIER();
+    const int64_t clip_bytes = (int64_t)(NC + 1) * P.T * 8;
+    const unsigned lane_bytes = 8u * ((unsigned)q * (unsigned)Ti + (unsigned)g);
+    const int n_carry = N - hop;                                                // samples a group hands on
+    const int n_round = (N + hop - 1) / hop < 8 ? (N + hop - 1) / hop : 8;
+
+    const int64_t worker = (int64_t)blockIdx.x * APQ_WAVES + wave;
+    const int64_t n_workers = (int64_t)gridDim.x * APQ_WAVES;
+    const int64_t grp_lo = P.n_groups * worker / n_workers, grp_hi = P.n_groups * (worker + 1) / n_workers;
+    if (grp_lo >= grp_hi) return;
+    // a stretch that starts inside a clip: the group before it, without stores
+    const bool warm = (grp_lo % P.groups_per_clip) != 0;
+    for (int64_t grp = warm ? grp_lo - 1 : grp_lo; grp < grp_hi; ++grp) {
+        const bool emit = grp >= grp_lo;
+        const int64_t b = grp / P.groups_per_clip;
+        const int t0 = (int)(grp - b * P.groups_per_clip) * 8;
+        const bool live = t0 + g < Ti;
+        const bool last = t0 + 8 >= Ti;                                         // last group of its clip
+        const ApOutBuf sb = ap_outbuf_make(const_cast<char *>(reinterpret_cast<const char *>(P.S)) + b * clip_bytes, clip_bytes);
+        ap_float2 v[R];
+        apq_inverse_frame<R>(sb, live ? lane_bytes : 0xF0000000u, Ti, t0, Sm + q * BS, Tt + q * BS, Ln, msrc, v);
+        // Overlap-add into the accumulator in n_round = ceil(N / hop) rounds: frames n_round apart do not overlap,
+        // so round r adds the frames g = r (mod n_round) with plain read-add-write (LDS float atomics cost ~150
+        // cycles per wave instruction here: 1.0 ms of a 1.5 ms kernel).  8-byte accesses when hop is even.
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) v[k1] = ap_mul2(v[k1], wv[k1]);
+        {
+            float *dst = acc + g * hop + 2 * R * Ln.k2;
+            const bool even_hop = (hop & 1) == 0;
+            for (int r = 0; r < n_round; ++r) {
+                if (live && g % n_round == r) {
+                    if (even_hop) {
+                        ap_float2 o[R];
+#pragma unroll
+                        for (int k1 = 0; k1 < R; ++k1) o[k1] = reinterpret_cast<ap_float2 *>(dst)[k1];
+#pragma unroll
+                        for (int k1 = 0; k1 < R; ++k1) reinterpret_cast<ap_float2 *>(dst)[k1] = ap_add(o[k1], v[k1]);
+                    } else {
+#pragma unroll
+                        for (int k1 = 0; k1 < R; ++k1) { dst[2 * k1] += v[k1].x; dst[2 * k1 + 1] += v[k1].y; }
+                    }
+                }
+                AP_WAVE_SYNC();
+            }
+        }
+        AP_WAVE_SYNC();
+        const int64_t p0 = (int64_t)t0 * hop;                                   // position of acc[0] in the un-trimmed signal
+        if (emit) {
+            float *yb = P.y + b * P.out_len;
+            // position fq hop + sidx of the accumulator, fq = 0 .. 7 (the whole span for the clip's last group)
+            const int n_fq = last ? (span + hop - 1) / hop : 8;
+            for (int sidx = lane; sidx < hop; sidx += 64) {
+                const float wss_all = WSS[sidx];
+                for (int fq = 0; fq < n_fq; ++fq) {
+                    const int j = fq * hop + sidx;
+                    if (j >= span) break;
+                    const int64_t i = p0 + j - P.out_offset;
+                    if (i < 0 || i >= P.out_len) continue;
+                    // window-sum-squares of the frames that exist and cover this position: frame t0 + fq - m reads
+                    // the window at sidx + m hop
+                    int lastf = t0 + fq;
+                    float wss;
+                    if (lastf <= Ti - 1 && (int64_t)p0 + j >= N - 1) {
+                        wss = wss_all;
+                    } else {
+                        int m_lo = lastf > Ti - 1 ? lastf - (Ti - 1) : 0;          // frames past T do not exist
+                        int m_hi = (N - 1 - sidx) / hop;                           // window index < N
+                        if (m_hi > lastf) m_hi = lastf;                            // frames before 0 do not exist
+                        wss = 0.0f;
+                        for (int m = m_hi; m >= m_lo; --m) wss += W2[sidx + m * hop];   // increasing frame index
+                    }
+                    yb[i] = acc[j] / fmaxf(wss, 1e-8f);
+                }
+            }
+            if (last) {                                                         // nothing covers the rest of the row
+                for (int64_t i = p0 + span - P.out_offset + lane; i < P.out_len; i += 64)
+                    if (i >= 0) yb[i] = 0.0f;
+            }
+        }
+        AP_WAVE_SYNC();
+        // the tail becomes the next group's carry (a new clip starts from zeros)
+        float cr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = lane + 64 * u;
+            cr[u] = (!last && j < n_carry) ? acc[8 * hop + j] : 0.0f;
+        }
+        AP_WAVE_SYNC();
+        for (int j = lane; j < span; j += 64) acc[j] = 0.0f;
+        AP_WAVE_SYNC();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = lane + 64 * u;
+            if (j < n_carry) acc[j] = cr[u];
+        }
+        AP_WAVE_SYNC();
+    }
+}

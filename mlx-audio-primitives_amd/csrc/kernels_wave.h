@@ -98,6 +98,11 @@ AP_DEV ap_float2 ap_clip16_load2(const ApClip16 &c, int64_t idx) {
 // output rows as a bounds-checked buffer: stores outside [0, bytes) are dropped
 struct ApOutBuf { char *base; int64_t bytes; };
 AP_DEV ApOutBuf ap_outbuf_make(void *base, int64_t bytes) { ApOutBuf o; o.base = (char *)base; o.bytes = bytes; return o; }
+AP_DEV ap_float2 ap_outbuf_load2(const ApOutBuf &o, unsigned lane_bytes, unsigned uniform_bytes) {
+    const uint64_t off = (uint64_t)lane_bytes + uniform_bytes;
+    if (lane_bytes < 0x80000000u && off + 8 <= (uint64_t)o.bytes) return *reinterpret_cast<const ap_float2 *>(o.base + off);
+    return ap_mk(0.0f, 0.0f);
+}
 AP_DEV void ap_outbuf_store2(const ApOutBuf &o, unsigned lane_bytes, unsigned uniform_bytes, ap_float2 v) {
     const uint64_t off = (uint64_t)lane_bytes + uniform_bytes;
     if (lane_bytes < 0x80000000u && off + 8 <= (uint64_t)o.bytes) *reinterpret_cast<ap_float2 *>(o.base + off) = v;
@@ -127,6 +132,10 @@ AP_DEV ap_float2 ap_clip_load2(ApClip c, int idx) {
 typedef __amdgpu_buffer_rsrc_t ApOutBuf;
 AP_DEV ApOutBuf ap_outbuf_make(void *base, int64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+AP_DEV ap_float2 ap_outbuf_load2(ApOutBuf o, unsigned lane_bytes, unsigned uniform_bytes) {
+    typedef int ap_i2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(ap_float2, __builtin_amdgcn_raw_buffer_load_b64(o, (int)lane_bytes, (int)uniform_bytes, 0));
 }
 AP_DEV void ap_outbuf_store2(ApOutBuf o, unsigned lane_bytes, unsigned uniform_bytes, ap_float2 v) {
     typedef int ap_i2 __attribute__((ext_vector_type(2)));

@@ -259,6 +259,10 @@ def istft_fused(S, hop, window, out_len, out_offset=None, grid_cap=0):
     out = np.zeros((B, out_len), np.float32)
     window = np.ascontiguousarray(window, np.float32)
     tw = twiddles(n_fft)
+    if n_fft in (512, 400, 256):
+        _check(lib().emu_istft8_fused_f32(_p(Sv), _i64(B), _i64(T), n_fft, hop, _p(window), _p(tw), _i64(out_offset),
+                                          _i64(out_len), grid_cap, _p(out)))
+        return out
     fn = lib().emu_istft_fused_f32 if n_fft == 2048 else lib().emu_istft1024_fused_f32
     _check(fn(_p(Sv), _i64(B), _i64(T), hop, _p(window), _p(tw), _i64(out_offset), _i64(out_len), grid_cap,
               _p(out)))

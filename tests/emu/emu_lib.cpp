@@ -251,6 +251,19 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
             return AP_OK;
         }
     }
+    if (n_fft == 512 || n_fft == 400 || n_fft == 256) {
+        ApIrfft8Params W;
+        int grid = 0;
+        const int R = n_fft / 16;
+        const int bs = R == 25 ? ApqGeom<25>::BS : R == 32 ? ApqGeom<32>::BS : ApqGeom<16>::BS;
+        if (ap_prepare_irfft8(W, P, B, R, bs, APQ_WAVES, &grid) == AP_OK) {
+            if (grid > 1) grid = 1;
+            if (R == 25) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<25>(W); });
+            else if (R == 32) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<32>(W); });
+            else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<16>(W); });
+            return AP_OK;
+        }
+    }
     emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_irfft_generic_kernel(P); });
     return AP_OK;
 }
@@ -330,6 +343,20 @@ int emu_istft1024_fused_f32(const float *S, int64_t B, int64_t T, int hop, const
     }
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
     emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_istft1024_wave_kernel(W); });
+    return AP_OK;
+}
+
+// fused ISTFT of the frames8 family (n_fft 512 / 400 / 256); grid_cap > 0 limits the workgroups
+int emu_istft8_fused_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const float *window, const float *tw,
+                         int64_t out_offset, int64_t out_len, int grid_cap, float *out) {
+    ApIstft8Params W;
+    int grid = 0;
+    if (ap_prepare_istft8(W, S, tw, B, T, n_fft, window, hop, out_offset, out_len, out, APQ_WAVES, &grid) != AP_OK)
+        return AP_ERR_UNSUPPORTED;
+    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+    if (n_fft == 512) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<32>(W); });
+    else if (n_fft == 400) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<25>(W); });
+    else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<16>(W); });
     return AP_OK;
 }
 

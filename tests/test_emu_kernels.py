@@ -408,3 +408,42 @@ def test_emu_spectral_statistics_from_audio(hop, L, B, center):
     for b in range(B):
         np.testing.assert_allclose(flat[b], ao.spectral_flatness(y[b], n_fft=2048, hop_length=hop, center=center)[0],
                                    rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_fft,B,T", [(512, 2, 19), (400, 3, 8), (256, 1, 33), (512, 1, 1)])
+def test_emu_irfft8_wave_kernel(n_fft, B, T):
+    """ap_irfft8_wave_kernel (kernels_frames8.h): the spectrum loaded in the forward transform's input
+    layout, Hermitian merge through lane permutes, the forward machinery on the conjugate - against
+    numpy.fft.irfft; imaginary parts of the DC and Nyquist bins are ignored; ragged last group."""
+    rng = np.random.default_rng(n_fft + T)
+    F = n_fft // 2 + 1
+    S = (rng.standard_normal((B, F, T)) + 1j * rng.standard_normal((B, F, T))).astype(np.complex64)
+    want = np.fft.irfft(S.astype(np.complex128), n=n_fft, axis=1).transpose(0, 2, 1)      # (B, T, n_fft)
+    got = eb.irfft_frames(S, n_fft)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("n_fft,hop,L,B,grid_cap", [
+    (512, 128, 9000, 3, 1), (512, 256, 5000, 2, 1), (512, 512, 7000, 1, 1), (512, 64, 3000, 2, 1),
+    (400, 160, 8000, 2, 1), (400, 100, 4100, 3, 1), (256, 64, 3000, 2, 1), (256, 33, 1500, 1, 1), (512, 128, 20000, 2, 2),
+])
+def test_emu_istft8_fused(n_fft, hop, L, B, grid_cap):
+    """Fused ISTFT of the frames8 family (ap_istft8_wave_kernel): LDS accumulation, carries along a
+    stretch, warm-up group of a stretch that starts inside a clip, clip change inside a stretch, tail and
+    zero fill after a clip's last group; `length` shorter and longer than the signal; no centre trim."""
+    rng = np.random.default_rng(n_fft + hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    wname = "boxcar" if hop == n_fft else "hann"          # a Hann window without overlap has wss -> 0 at every seam
+    S = ao.stft(y, n_fft=n_fft, hop_length=hop, window=wname)
+    win = ao.padded_window(wname, n_fft, n_fft)
+    for length in (L, L - 333, L + 60, L + 700):
+        out = eb.istft_fused(S, hop, win, length, grid_cap=grid_cap)
+        want = ao.istft(S, hop_length=hop, n_fft=n_fft, length=length, window=wname)
+        # past L + 60 the window-sum-squares falls towards the 1e-8 floor and the division amplifies the
+        # 1e-7 differences of any two irfft implementations: there only the zero fill is compared
+        np.testing.assert_allclose(out[:, :L + 60], want[:, :L + 60], atol=1e-5)
+        np.testing.assert_array_equal(out[:, L + n_fft // 2:], want[:, L + n_fft // 2:])
+    out = eb.istft_fused(S, hop, win, L + n_fft, out_offset=0, grid_cap=grid_cap)      # center=False reconstruction
+    want = ao.istft(S, hop_length=hop, n_fft=n_fft, center=False, length=L + n_fft, window=wname)
+    np.testing.assert_allclose(out[:, n_fft // 2:L + n_fft // 2], want[:, n_fft // 2:L + n_fft // 2], atol=1e-5)

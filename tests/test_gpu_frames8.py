@@ -107,3 +107,43 @@ def test_frames8_mfcc_global_max_and_shuffle():
     S = host(ap.melspectrogram(dev(y), sr=22050, n_fft=512, hop_length=128, n_mels=64))
     Sp = host(ap.melspectrogram(dev(y[perm]), sr=22050, n_fft=512, hop_length=128, n_mels=64))
     np.testing.assert_array_equal(Sp, S[perm])
+
+
+@pytest.mark.parametrize("n_fft,hop,B,L", [(512, 128, 3, 22050), (512, 256, 2, 9001), (512, 64, 2, 5000), (400, 160, 4, 16000),
+                                           (400, 100, 2, 4100), (256, 64, 5, 8000), (256, 33, 1, 1500),
+                                           (512, 128, 300, 9000), (400, 160, 700, 4000)])
+def test_istft_frames8_fused(n_fft, hop, B, L):
+    """Fused ISTFT of the frames8 family (irfft + overlap-add + normalisation + trim in one kernel) against
+    the oracle and the two-kernel route (AP_ISTFT8_UNFUSED): round trip <= 1e-5, `length` shorter / longer,
+    stretches that start inside clips and cross clip ends."""
+    import os
+    rng = np.random.default_rng(n_fft + hop + B)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ap.stft(dev(y), n_fft=n_fft, hop_length=hop)
+    yr = host(ap.istft(S, hop_length=hop, length=L))
+    np.testing.assert_allclose(yr, y, atol=1e-5)                          # README.md:118
+    Sh = host(S)
+    for b in sorted(set([0, B - 1])):
+        for length in (L - 333, L + 40):
+            got = host(ap.istft(S[b], hop_length=hop, length=length))
+            want = ao.istft(Sh[b], hop_length=hop, n_fft=n_fft, length=length)
+            np.testing.assert_allclose(got[:L + 40], want[:L + 40], atol=1e-5)
+    os.environ["AP_ISTFT8_UNFUSED"] = "1"
+    try:
+        y2 = host(ap.istft(S, hop_length=hop, length=L))
+    finally:
+        del os.environ["AP_ISTFT8_UNFUSED"]
+    np.testing.assert_allclose(yr, y2, atol=2e-6)
+
+
+def test_istft_frames8_no_centre_and_fallback_hops():
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal((2, 6000)).astype(np.float32)
+    S = ap.stft(dev(y), n_fft=512, hop_length=128, center=False)
+    got = host(ap.istft(S, hop_length=128, center=False))
+    want = ao.istft(host(S), hop_length=128, n_fft=512, center=False)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got[:, 512:-512], want[:, 512:-512], atol=1e-5)
+    # hop below n_fft / 8: the carry of one group no longer covers the overlap - two-kernel route
+    S = ap.stft(dev(y), n_fft=512, hop_length=32)
+    np.testing.assert_allclose(host(ap.istft(S, hop_length=32, length=6000)), y, atol=1e-5)
