@@ -250,7 +250,7 @@ static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P,
 static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, int64_t B, const int32_t *plan,
                                      const int32_t *desc, int n_waves, int x_complex, int partial_off,
                                      int *n_pass, int *grid) {
-    if (!ap_clip_loads_ok(P)) return 1;
+    // (reflect / edge padding and odd hops: the caller picks the kernel's index-remapping input mode)
     if (P.n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 1;
     if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;          // 32-bit frame and sample arithmetic in the loop
     W.y = P.y;

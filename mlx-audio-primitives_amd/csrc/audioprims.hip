@@ -318,6 +318,9 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
                 if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
                 W.max_key = max_key_dev;
             }
+            if (!ap_clip_loads_ok(P))      // reflect / edge padding, odd hops: index-remapped loads for the edge frames
+                return power == 2.0f ? ap_launch_mel_run<2, 2>(W, n_pass, grid, stream)
+                                     : ap_launch_mel_run<1, 2>(W, n_pass, grid, stream);
             return power == 2.0f ? ap_launch_mel_run<2>(W, n_pass, grid, stream)
                                  : ap_launch_mel_run<1>(W, n_pass, grid, stream);
         }

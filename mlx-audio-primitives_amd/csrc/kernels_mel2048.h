@@ -232,7 +232,7 @@ AP_DEV void apm_split(const ap_float2 *X, const ApwLane &c, const ap_float2 (&ws
 
 template <int PMODE, int NPASS, int HOPJ, int IN16 = 0, int NW = APM_WAVES, int REGS = APM_REGS>
 __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWaveParams P) {
-    static_assert(!IN16 || (REGS & APM_REG_WIN), "the PCM scale rides on the register-resident window");
+    static_assert(IN16 != 1 || (REGS & APM_REG_WIN), "the PCM scale rides on the register-resident window");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = AP_UNIFORM(tid >> 6);
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         winr[j] = (REGS & APM_REG_WIN) ? reinterpret_cast<const ap_float2 *>(P.window)[lane + 64 * j] : ap_mk(0.0f, 0.0f);
-        if (IN16) winr[j] = ap_scale(winr[j], 1.0f / 32768.0f);      // 16-bit PCM -> [-1, 1): folded into the window
+        if (IN16 == 1) winr[j] = ap_scale(winr[j], 1.0f / 32768.0f);      // 16-bit PCM -> [-1, 1): folded into the window
         t1r[j] = (REGS & APM_REG_TW1) ? P.tw[(2 * lane * j) & 2047] : ap_mk(0.0f, 0.0f);        // W_1024^(lane j)
         t2r[j] = (REGS & APM_REG_TW2) ? ap_scale(P.tw[32 * (lane & 3) * j], lm.sg) : ap_mk(0.0f, 0.0f);
     }
@@ -311,8 +311,18 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
         // IN16: P.y points at int16 samples (the ingest conversion rides on the
         // sample loads; half the HBM read bytes of the float32 path)
         const int16_t *y16 = reinterpret_cast<const int16_t *>(P.y);
-        ApClip clip = ap_clip_make(P.y + (IN16 ? 0 : b * P.L), IN16 ? 0 : P.L);
-        ApClip16 clip16 = ap_clip16_make(y16 + (IN16 ? b * P.L : 0), IN16 ? P.L : 0);
+        // IN16 == 2: float32 samples with reflect / edge padding (or odd hops): the frames that reach over a clip
+        // end take the index-remapping loader, every other frame the bounds-checked loads
+        ApClip clip = ap_clip_make(P.y + (IN16 == 1 ? 0 : b * P.L), IN16 == 1 ? 0 : P.L);
+        ApClip16 clip16 = ap_clip16_make(y16 + (IN16 == 1 ? b * P.L : 0), IN16 == 1 ? P.L : 0);
+        auto ld2 = [&](int64_t bb, int base, int p) -> ap_float2 {
+            if (IN16 == 1) return ap_clip16_load2(clip16, p);
+            if (IN16 == 2 && !(base >= 0 && (int64_t)base + 2 * APW_NC <= P.L)) {
+                const float *yb = P.y + bb * P.L;
+                return ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            }
+            return ap_clip_load2(clip, p);
+        };
         // Sample pair j of the frame in hand lives in raw[(j + HOPJ rot) & 15]: with hop = 128 HOPJ, pair j of
         // frame t + 1 is pair j + HOPJ of frame t, so the HOPJ new pairs of the next frame overwrite the HOPJ
         // oldest registers and nothing moves.  `rot` has to be a compile-time constant for that (registers
@@ -326,7 +336,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int p = base + 2 * (lane + 64 * j);
-                raw[(j + HOPJ * ROT) & 15] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                raw[(j + HOPJ * ROT) & 15] = ld2(b, base, p);
             }
         };
         load_frame(t, std::integral_constant<int, 0>());
@@ -364,7 +374,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
             AP_SCHED_FENCE();
             if (more) {
                 if (clip_ends) {                  // next clip starts
-                    if (IN16) clip16 = ap_clip16_make(y16 + (b + 1) * P.L, P.L);
+                    if (IN16 == 1) clip16 = ap_clip16_make(y16 + (b + 1) * P.L, P.L);
                     else clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
                 }
                 // hop = 128 HOPJ: only the HOPJ new pairs are loaded, the shared samples stay where they are;
@@ -375,13 +385,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
 #pragma unroll
                 for (int j = 16 - HOPJ; j < 16; ++j) {
                     const int p = base + 2 * (lane + 64 * j);
-                    raw[(j + HOPJ * NROT) & 15] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                    raw[(j + HOPJ * NROT) & 15] = ld2(clip_ends ? b + 1 : b, base, p);
                 }
                 if (HOPJ == 0 || clip_ends) {
 #pragma unroll
                     for (int j = 0; j < 16 - HOPJ; ++j) {
                         const int p = base + 2 * (lane + 64 * j);
-                        raw[(j + HOPJ * NROT) & 15] = IN16 ? ap_clip16_load2(clip16, p) : ap_clip_load2(clip, p);
+                        raw[(j + HOPJ * NROT) & 15] = ld2(clip_ends ? b + 1 : b, base, p);
                     }
                 }
             }

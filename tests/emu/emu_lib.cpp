@@ -172,8 +172,11 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
             ap_prepare_mel_run(W, P, B, plan, desc, APM_WAVES, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
             if (grid > 1) grid = 1;   // exercise the persistent frame loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
-#define EMU_RUN(PM, NP) do { if (W.hopj == 4) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 4>(W); }); \
-                             else emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 0>(W); }); } while (0)
+            const bool padgen = !ap_clip_loads_ok(P);
+#define EMU_RUN(PM, NP) do { if (W.hopj == 4 && !padgen) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 4>(W); }); \
+                             else if (W.hopj == 4) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 4, 2>(W); }); \
+                             else if (!padgen) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 0>(W); }); \
+                             else emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 0, 2>(W); }); } while (0)
             if (power == 2.0f) { if (n_pass == 1) EMU_RUN(2, 1); else if (n_pass == 2) EMU_RUN(2, 2); else if (n_pass == 3) EMU_RUN(2, 3); else EMU_RUN(2, 4); }
             else { if (n_pass == 1) EMU_RUN(1, 1); else if (n_pass == 2) EMU_RUN(1, 2); else if (n_pass == 3) EMU_RUN(1, 3); else EMU_RUN(1, 4); }
 #undef EMU_RUN

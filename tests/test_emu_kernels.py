@@ -447,3 +447,19 @@ def test_emu_istft8_fused(n_fft, hop, L, B, grid_cap):
     out = eb.istft_fused(S, hop, win, L + n_fft, out_offset=0, grid_cap=grid_cap)      # center=False reconstruction
     want = ao.istft(S, hop_length=hop, n_fft=n_fft, center=False, length=L + n_fft, window=wname)
     np.testing.assert_allclose(out[:, n_fft // 2:L + n_fft // 2], want[:, n_fft // 2:L + n_fft // 2], atol=1e-5)
+
+
+@pytest.mark.parametrize("hop,pad_mode,L,B,power", [(512, "reflect", 9000, 3, 2.0), (512, "edge", 7001, 2, 1.0),
+                                                     (333, "constant", 6000, 2, 2.0), (300, "reflect", 5000, 1, 2.0)])
+def test_emu_run_kernel_index_remapped_edges(hop, pad_mode, L, B, power):
+    """The run kernel's third input mode: reflect / edge padding and odd hops - frames that reach over a clip end
+    load through the index remap, the others through the bounds-checked loads, the register reuse between
+    consecutive frames (hop 512) unchanged."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 2048, 2048)
+    fb = ao.mel_filterbank(22050, 2048, 128)
+    R = ao.melspectrogram(y, sr=22050, n_fft=2048, hop_length=hop, n_mels=128, power=power, pad_mode=pad_mode)
+    A, amax = eb.melspec(y, 2048, hop, win, fb, power=power, pad_mode=PM[pad_mode], return_max=True)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()
