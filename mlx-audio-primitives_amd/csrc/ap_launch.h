@@ -340,7 +340,7 @@ template <class W8>
 static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bool mel, const int32_t *plan,
                                      const int32_t *desc, int n_waves, const ApFrames8Geom &G, int *grid) {
     if (P.plan.n != 16 * G.R) return 1;
-    if (!ap_clip_loads_ok(P)) return 1;
+    // (reflect / edge padding, odd hops: the caller launches the PADGEN instantiation)
     if (P.T > (1 << 19) || P.L > (1 << 28)) return 1;      // 32-bit frame, sample and output-offset arithmetic (a clip's STFT rows < 2 GiB)
     if (mel) {
         if (!(plan && desc && (desc[0] & AP_PLAN_BANDED) && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
@@ -361,6 +361,7 @@ static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bo
     W.n_groups = W.groups_per_clip * B;
     W.hop = P.hop;
     W.pad = P.pad;
+    W.pad_mode = P.pad_mode;
     W.n_mels = mel ? P.n_mels : 0;
     W.wmax = (mel && desc[15] > 2) ? G.wmax_max : G.wmax_max - 32;
     W.power = P.power;

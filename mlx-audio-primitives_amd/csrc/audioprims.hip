@@ -128,8 +128,11 @@ static int ap_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *plan,
         if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
         W.max_key = max_key_dev;
     }
-    auto kern = power == 2.0f ? ap_mel8_wave_kernel<R, 2> : power == 1.0f ? ap_mel8_wave_kernel<R, 1>
-                                                                          : ap_mel8_wave_kernel<R, 0>;
+    const bool padgen = !ap_clip_loads_ok(P);             // reflect / edge padding, odd hops
+    auto kern = padgen ? (power == 2.0f ? ap_mel8_wave_kernel<R, 2, 1> : power == 1.0f ? ap_mel8_wave_kernel<R, 1, 1>
+                                                                                        : ap_mel8_wave_kernel<R, 0, 1>)
+                       : (power == 2.0f ? ap_mel8_wave_kernel<R, 2> : power == 1.0f ? ap_mel8_wave_kernel<R, 1>
+                                                                                    : ap_mel8_wave_kernel<R, 0>);
     int rc = ap_allow_lds(kern, W.lds_bytes);
     if (rc != AP_OK) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
@@ -143,9 +146,10 @@ static int ap_launch_stft8(const ApStftParams &P, int64_t B, void *stream, bool 
     int grid = 0;
     *handled = false;
     if (ap_prepare_frames8(W, P, B, false, nullptr, nullptr, APQ_WAVES, ap_frames8_geom<R>(), &grid) != AP_OK) return AP_OK;
-    int rc = ap_allow_lds(ap_stft8_wave_kernel<R>, W.lds_bytes);
+    auto kern = ap_clip_loads_ok(P) ? ap_stft8_wave_kernel<R, 0> : ap_stft8_wave_kernel<R, 1>;
+    int rc = ap_allow_lds(kern, W.lds_bytes);
     if (rc != AP_OK) return rc;
-    hipLaunchKernelGGL(ap_stft8_wave_kernel<R>, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
     *handled = true;
     return ap_check_launch("ap_stft_f32(frames8)");
 }

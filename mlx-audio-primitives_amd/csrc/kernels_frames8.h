@@ -53,7 +53,7 @@ struct ApFrames8Params {
     float *out;                // mel: (B, M, T); STFT: (B, n_fft/2 + 1, T) complex64
     unsigned *max_key;
     int64_t L, T, n_clips, groups_per_clip, n_groups;
-    int hop, pad, n_mels, wmax;   // wmax: floats per filter row of the LDS weight table (32 or 64, + 4 for even R)
+    int hop, pad, pad_mode, n_mels, wmax;   // pad_mode: used by the PADGEN instantiations only.   wmax: floats per filter row of the LDS weight table (32 or 64, + 4 for even R)
     float power;
     int off_t, off_s, off_win, off_w, off_lo, off_plane, lds_bytes;
 };
@@ -213,7 +213,9 @@ AP_DEV void apq_split(const ap_float2 (&v)[R], const ap_float2 *Srow, const ApqL
 
 // one wave's stretch of 8-frame groups: sample loads one group ahead, window, transform; body(v, b, t0)
 // gets the lane's bins of the packed transform
-template <int R, class Body>
+// PADGEN: reflect / edge padding and odd hops - a lane whose frame reaches over a clip end loads through the
+// index remap (ap_load_padded), the others through the bounds-checked loads
+template <int R, int PADGEN, class Body>
 AP_DEV void apq_group_loop(const ApFrames8Params &P, const ApqLane &Ln, const ap_float2 *Trow,
                            const ap_float2 *WINP, int wave, Body &&body) {
     constexpr bool WIN_REGS = ApqGeom<R>::WIN_REGS;
@@ -231,12 +233,20 @@ AP_DEV void apq_group_loop(const ApFrames8Params &P, const ApqLane &Ln, const ap
     int t0 = (int)(grp_lo - b * P.groups_per_clip) * 8;
     ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
     ap_float2 raw[R];
-    auto load_group = [&](int tt0) {
-        const int base = (tt0 + Ln.g) * P.hop - P.pad + 2 * Ln.q;
+    auto load_group = [&](int64_t bb, int tt0) {
+        const int fbase = (tt0 + Ln.g) * P.hop - P.pad;
+        const int base = fbase + 2 * Ln.q;
+        if (PADGEN && !(fbase >= 0 && (int64_t)fbase + 16 * R <= P.L)) {
+            const float *yb = P.y + bb * P.L;
 #pragma unroll
-        for (int r = 0; r < R; ++r) raw[r] = ap_clip_load2(clip, base + 16 * r);
+            for (int r = 0; r < R; ++r)
+                raw[r] = ap_mk(ap_load_padded(yb, P.L, base + 16 * r, P.pad_mode), ap_load_padded(yb, P.L, base + 16 * r + 1, P.pad_mode));
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw[r] = ap_clip_load2(clip, base + 16 * r);
+        }
     };
-    load_group(t0);
+    load_group(b, t0);
     // (the loop leaves through `more`: were the prefetch skipped on a path that re-enters the loop, the
     // register allocator would copy all R pairs at that merge)
     for (int64_t grp = grp_lo;; ++grp) {
@@ -261,7 +271,7 @@ AP_DEV void apq_group_loop(const ApFrames8Params &P, const ApqLane &Ln, const ap
         const bool more = grp + 1 < grp_hi;
         if (more) {                                       // next group, in flight during this one
             if (clip_ends) clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
-            load_group(clip_ends ? 0 : t0 + 8);
+            load_group(clip_ends ? b + 1 : b, clip_ends ? 0 : t0 + 8);
         }
         AP_SCHED_FENCE();
         apq_transform<R>(v, Trow, Ln);
@@ -274,7 +284,7 @@ AP_DEV void apq_group_loop(const ApFrames8Params &P, const ApqLane &Ln, const ap
 // ---------------------------------------------------------------------------------------------
 // mel-spectrogram
 // ---------------------------------------------------------------------------------------------
-template <int R, int PMODE>
+template <int R, int PMODE, int PADGEN = 0>
 __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrames8Params P) {
     typedef ApqGeom<R> G;
     constexpr int NC = G::NC, BS = G::BS, PS = G::PS, PADB = G::PADB;
@@ -334,7 +344,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
 
     float vmax = -INFINITY;
     const int Ti = (int)P.T;
-    apq_group_loop<R>(P, Ln, Tt + q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
+    apq_group_loop<R, PADGEN>(P, Ln, Tt + q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
         // ---- paired real split + power: this lane's bins k = k1 + R k2 --------------------
         float *pl = plane + g * PS + BS * Ln.k2;
         apq_split<R>(v, St + q * BS, Ln, [&](int k1, ap_float2 x) { pl[k1] = apw_pow2x<PMODE>(x.x, x.y, P.power); });
@@ -406,7 +416,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
 // ---------------------------------------------------------------------------------------------
 // STFT: out (B, 8R + 1, T) complex64
 // ---------------------------------------------------------------------------------------------
-template <int R>
+template <int R, int PADGEN = 0>
 __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_stft8_wave_kernel(ApFrames8Params P) {
     typedef ApqGeom<R> G;
     constexpr int NC = G::NC, BS = G::BS;
@@ -429,7 +439,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_stft8_wave_kernel(ApFram
     // lane part of a store's address is (bin block R k2, frame g), the uniform part (bin k1, group t0).
     const unsigned lane_bytes = 8u * ((unsigned)(R * Ln.k2) * (unsigned)Ti + (unsigned)Ln.g);
     const int64_t clip_bytes = (int64_t)(NC + 1) * P.T * 8;
-    apq_group_loop<R>(P, Ln, Tt + Ln.q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
+    apq_group_loop<R, PADGEN>(P, Ln, Tt + Ln.q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
         const ApOutBuf ob = ap_outbuf_make(reinterpret_cast<char *>(P.out) + b * clip_bytes, clip_bytes);
         const unsigned lb = t0 + Ln.g < Ti ? lane_bytes : 0xF0000000u;          // frames past T: parked
         apq_split<R>(v, St + Ln.q * BS, Ln, [&](int k1, ap_float2 x) {

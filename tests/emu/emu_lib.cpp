@@ -42,6 +42,12 @@ static bool emu_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *pla
     if (ap_prepare_frames8(W, P, B, true, plan, desc, APQ_WAVES, G, &grid) != AP_OK) return false;
     if (grid > 1) grid = 1;   // exercise the persistent group loop
     if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
+    if (!ap_clip_loads_ok(P)) {
+        if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2, 1>(W); });
+        else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1, 1>(W); });
+        else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0, 1>(W); });
+        return true;
+    }
     if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2>(W); });
     else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1>(W); });
     else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0>(W); });
@@ -55,7 +61,8 @@ static bool emu_launch_stft8(const ApStftParams &P, int64_t B) {
     const ApFrames8Geom G = {R, ApqGeom<R>::BS, ApqGeom<R>::PS, ApqGeom<R>::WMAX, ApqGeom<R>::WIN_REGS ? 0 : 1};
     if (ap_prepare_frames8(W, P, B, false, nullptr, nullptr, APQ_WAVES, G, &grid) != AP_OK) return false;
     if (grid > 1) grid = 1;
-    emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R>(W); });
+    if (ap_clip_loads_ok(P)) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R, 0>(W); });
+    else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R, 1>(W); });
     return true;
 }
 

@@ -463,3 +463,20 @@ def test_emu_run_kernel_index_remapped_edges(hop, pad_mode, L, B, power):
     A, amax = eb.melspec(y, 2048, hop, win, fb, power=power, pad_mode=PM[pad_mode], return_max=True)
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
     assert amax == A.max()
+
+
+@pytest.mark.parametrize("n_fft,hop,pad_mode,L,B", [(512, 128, "reflect", 4000, 2), (512, 77, "constant", 3001, 2),
+                                                     (400, 160, "edge", 5000, 3), (256, 64, "reflect", 1500, 1),
+                                                     (400, 33, "reflect", 2000, 1)])
+def test_emu_frames8_index_remapped_edges(n_fft, hop, pad_mode, L, B):
+    """PADGEN instantiations of kernels_frames8.h: reflect / edge padding and centred frames at odd hops."""
+    rng = np.random.default_rng(n_fft + hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", n_fft, n_fft)
+    want = np.stack([ao.stft(y[b], n_fft=n_fft, hop_length=hop, pad_mode=pad_mode) for b in range(B)])
+    np.testing.assert_allclose(eb.stft(y, n_fft, hop, win, pad_mode=PM[pad_mode]), want, rtol=1e-4, atol=1e-4)
+    fb = ao.mel_filterbank(16000, n_fft, 40)
+    R = ao.melspectrogram(y, sr=16000, n_fft=n_fft, hop_length=hop, n_mels=40, pad_mode=pad_mode)
+    A, amax = eb.melspec(y, n_fft, hop, win, fb, pad_mode=PM[pad_mode], return_max=True)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()                 # only the fused kernels hand the maximum back

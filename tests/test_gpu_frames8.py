@@ -57,8 +57,9 @@ def test_stft_frames8(n_fft, hop, B, L, center):
     (256, dict(sr=8000, hop_length=64, n_mels=32), 4, 8000),
     (256, dict(sr=16000, hop_length=100, n_mels=64, fmin=100.0, norm=None), 2, 5000),
     (400, dict(sr=16000, hop_length=160, n_mels=40), 2, 16000),                       # Whisper kernel, wide rows
-    # fallbacks to the LDS engine
+    # index-remapped edge frames (PADGEN instantiation), then the fallbacks to the LDS engine
     (512, dict(sr=22050, hop_length=128, n_mels=64, pad_mode="reflect"), 2, 9000),
+    (400, dict(sr=16000, hop_length=160, n_mels=80, pad_mode="edge"), 300, 4000),
     (512, dict(sr=22050, hop_length=128, n_mels=160), 2, 9000),
     (512, dict(sr=22050, hop_length=128, n_mels=10), 2, 9000),
 ])
@@ -147,3 +148,18 @@ def test_istft_frames8_no_centre_and_fallback_hops():
     # hop below n_fft / 8: the carry of one group no longer covers the overlap - two-kernel route
     S = ap.stft(dev(y), n_fft=512, hop_length=32)
     np.testing.assert_allclose(host(ap.istft(S, hop_length=32, length=6000)), y, atol=1e-5)
+
+
+@pytest.mark.parametrize("pad_mode", ["reflect", "edge"])
+@pytest.mark.parametrize("n_fft,hop,B,L", [(512, 128, 3, 9001), (400, 160, 200, 4000), (256, 64, 2, 3000), (2048, 512, 3, 30001)])
+def test_stft_and_mel_pad_modes_on_the_wave_kernels(pad_mode, n_fft, hop, B, L):
+    """reflect / edge padding on the eight-frames-per-wave kernels and the n_fft = 2048 run kernel: only the
+    frames that reach over a clip end take the index remap."""
+    rng = np.random.default_rng(n_fft + B)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = host(ap.stft(dev(y), n_fft=n_fft, hop_length=hop, pad_mode=pad_mode))
+    M = host(ap.melspectrogram(dev(y), sr=16000, n_fft=n_fft, hop_length=hop, n_mels=40, pad_mode=pad_mode))
+    for b in sorted(set([0, B - 1])):
+        np.testing.assert_allclose(S[b], ao.stft(y[b], n_fft=n_fft, hop_length=hop, pad_mode=pad_mode), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(M[b], ao.melspectrogram(y[b], sr=16000, n_fft=n_fft, hop_length=hop, n_mels=40,
+                                                           pad_mode=pad_mode), rtol=1e-4, atol=1e-3)
