@@ -337,3 +337,8 @@ def spectral_from_audio(y, sr, hop, window, center=True, power=1.0, p=2.0, norm=
                                         _p(freq), f(power), f(p), int(norm), f(roll_percent), f(amin),
                                         g("centroid"), g("bandwidth"), g("rolloff"), g("flatness")))
     return outs
+
+
+def lds_overruns():
+    """Launches since the library was loaded that wrote past the dynamic LDS their host code asked for."""
+    return int(lib().emu_lds_overrun_count())

@@ -43,14 +43,14 @@ static bool emu_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *pla
     if (grid > 1) grid = 1;   // exercise the persistent group loop
     if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
     if (!ap_clip_loads_ok(P)) {
-        if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2, 1>(W); });
-        else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1, 1>(W); });
-        else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0, 1>(W); });
+        if (power == 2.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2, 1>(W); });
+        else if (power == 1.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1, 1>(W); });
+        else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0, 1>(W); });
         return true;
     }
-    if (power == 2.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2>(W); });
-    else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1>(W); });
-    else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0>(W); });
+    if (power == 2.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 2>(W); });
+    else if (power == 1.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 1>(W); });
+    else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_mel8_wave_kernel<R, 0>(W); });
     return true;
 }
 
@@ -61,14 +61,14 @@ static bool emu_launch_stft8(const ApStftParams &P, int64_t B) {
     const ApFrames8Geom G = {R, ApqGeom<R>::BS, ApqGeom<R>::PS, ApqGeom<R>::WMAX, ApqGeom<R>::WIN_REGS ? 0 : 1};
     if (ap_prepare_frames8(W, P, B, false, nullptr, nullptr, APQ_WAVES, G, &grid) != AP_OK) return false;
     if (grid > 1) grid = 1;
-    if (ap_clip_loads_ok(P)) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R, 0>(W); });
-    else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R, 1>(W); });
+    if (ap_clip_loads_ok(P)) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R, 0>(W); });
+    else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_stft8_wave_kernel<R, 1>(W); });
     return true;
 }
 
 struct EmuFftOps {                       // kernel launches of ap_resample_fft_compose on the CPU emulator
     int leg(const ApCfftParams &C, int64_t B) {
-        emu_launch((unsigned)(C.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(C); });
+        emu_lds_limit(C.tile.lds_bytes), emu_launch((unsigned)(C.tiles_per_signal * B), AP_BLOCK, [&] { ap_cfft_strided_kernel(C); });
         return AP_OK;
     }
     int spectrum(const ap_float2 *X, int64_t Nx, ap_float2 *Y, int64_t num, int64_t B) {
@@ -137,9 +137,9 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
         if (ap_prepare_stft_wave(W, P, B, &grid) == AP_OK) {
             if (grid > 2) grid = 2;   // exercise the persistent group loop
             if (ap_clip_loads_ok(W))
-                emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<0>(W); });
+                emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<0>(W); });
             else
-                emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<1>(W); });
+                emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_wave_kernel<1>(W); });
             return AP_OK;
         }
     }
@@ -148,7 +148,7 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
         int grid = 0;
         if (ap_prepare_stft_wave512(W, P, B, APHS_WAVES, APH_X_COMPLEX, APHS_OB_ROWS * APHS_OB_ROW, &grid) == AP_OK) {
             if (grid > 2) grid = 2;   // exercise the persistent group loop and the carries
-            emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_stft1024_wave_kernel(W); });
+            emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_stft1024_wave_kernel(W); });
             return AP_OK;
         }
     }
@@ -158,7 +158,7 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
     }
     if (ap_clip_loads_ok(P) ? emu_launch_ct<0, 0>(P, n_fft, B) : emu_launch_ct<0, 1>(P, n_fft, B))
         return AP_OK;
-    emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
+    emu_lds_limit(P.tile.lds_bytes), emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
     return AP_OK;
 }
 
@@ -183,7 +183,8 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
 #define EMU_RUN(PM, NP) do { if (W.hopj == 4 && !padgen) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 4>(W); }); \
                              else if (W.hopj == 4) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 4, 2>(W); }); \
                              else if (!padgen) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 0>(W); }); \
-                             else emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 0, 2>(W); }); } while (0)
+                             else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_mel2048_run_kernel<PM, NP, 0, 2>(W); }); } while (0)
+            emu_lds_limit(W.lds_bytes);
             if (power == 2.0f) { if (n_pass == 1) EMU_RUN(2, 1); else if (n_pass == 2) EMU_RUN(2, 2); else if (n_pass == 3) EMU_RUN(2, 3); else EMU_RUN(2, 4); }
             else { if (n_pass == 1) EMU_RUN(1, 1); else if (n_pass == 2) EMU_RUN(1, 2); else if (n_pass == 3) EMU_RUN(1, 3); else EMU_RUN(1, 4); }
 #undef EMU_RUN
@@ -193,12 +194,12 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
             if (grid > 1) grid = 1;   // exercise the persistent tile loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
             const bool gen = !ap_clip_loads_ok(W);
-            if (power == 2.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 0>(W); });
-            else if (power == 2.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 1>(W); });
-            else if (power == 1.0f && !gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 0>(W); });
-            else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 1>(W); });
-            else if (!gen) emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 0>(W); });
-            else emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 1>(W); });
+            if (power == 2.0f && !gen) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 0>(W); });
+            else if (power == 2.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<2, 1>(W); });
+            else if (power == 1.0f && !gen) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 0>(W); });
+            else if (power == 1.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<1, 1>(W); });
+            else if (!gen) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 0>(W); });
+            else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APW_WAVES, [&] { ap_mel2048_wave_kernel<0, 1>(W); });
             return AP_OK;
         }
     }
@@ -214,9 +215,9 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         if (ap_prepare_mel_wave512(W, P, B, plan, desc, APH_WAVES, APH_X_COMPLEX, APH_PASSES, &grid) == AP_OK) {
             if (grid > 1) grid = 1;   // exercise the persistent frame loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
-            if (power == 2.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2>(W); });
-            else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1>(W); });
-            else emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0>(W); });
+            if (power == 2.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2>(W); });
+            else if (power == 1.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1>(W); });
+            else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0>(W); });
             return AP_OK;
         }
     }
@@ -224,7 +225,7 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         if (ap_clip_loads_ok(P) ? emu_launch_ct<1, 0>(P, n_fft, B) : emu_launch_ct<1, 1>(P, n_fft, B))
             return AP_OK;
     }
-    emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<1>(P); });
+    emu_lds_limit(P.tile.lds_bytes), emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<1>(P); });
     return AP_OK;
 }
 
@@ -257,7 +258,7 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
         int grid = 0;
         if (ap_prepare_irfft_wave(W, P, B, &grid) == AP_OK) {
             if (grid > 2) grid = 2;
-            emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<0>(W); });
+            emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<0>(W); });
             return AP_OK;
         }
     }
@@ -268,13 +269,13 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
         const int bs = R == 25 ? ApqGeom<25>::BS : R == 32 ? ApqGeom<32>::BS : ApqGeom<16>::BS;
         if (ap_prepare_irfft8(W, P, B, R, bs, APQ_WAVES, &grid) == AP_OK) {
             if (grid > 1) grid = 1;
-            if (R == 25) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<25>(W); });
-            else if (R == 32) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<32>(W); });
-            else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<16>(W); });
+            if (R == 25) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<25>(W); });
+            else if (R == 32) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<32>(W); });
+            else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_irfft8_wave_kernel<16>(W); });
             return AP_OK;
         }
     }
-    emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_irfft_generic_kernel(P); });
+    emu_lds_limit(P.tile.lds_bytes), emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_irfft_generic_kernel(P); });
     return AP_OK;
 }
 
@@ -352,7 +353,7 @@ int emu_istft1024_fused_f32(const float *S, int64_t B, int64_t T, int hop, const
         grid = (int)(W.n_groups < 256 ? W.n_groups : 256);
     }
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-    emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_istft1024_wave_kernel(W); });
+    emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_istft1024_wave_kernel(W); });
     return AP_OK;
 }
 
@@ -364,9 +365,9 @@ int emu_istft8_fused_f32(const float *S, int64_t B, int64_t T, int n_fft, int ho
     if (ap_prepare_istft8(W, S, tw, B, T, n_fft, window, hop, out_offset, out_len, out, APQ_WAVES, &grid) != AP_OK)
         return AP_ERR_UNSUPPORTED;
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-    if (n_fft == 512) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<32>(W); });
-    else if (n_fft == 400) emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<25>(W); });
-    else emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<16>(W); });
+    if (n_fft == 512) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<32>(W); });
+    else if (n_fft == 400) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<25>(W); });
+    else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APQ_WAVES, [&] { ap_istft8_wave_kernel<16>(W); });
     return AP_OK;
 }
 
@@ -390,7 +391,7 @@ int emu_istft_fused_f32(const float *S, int64_t B, int64_t T, int hop, const flo
         grid = (int)(W.n_groups < 256 ? W.n_groups : 256);
     }
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-    emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<1>(W); });
+    emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<1>(W); });
     return AP_OK;
 }
 
@@ -469,7 +470,8 @@ int emu_spectral_audio_f32(const float *y, int64_t B, int64_t L, int hop, const 
 #define EMU_SPEC(PM, FL) do { if (W.hopj == 4 && p == 2.0f) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 4, FL, 0>(W); }); \
                               else if (W.hopj == 4) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 4, FL, 1>(W); }); \
                               else if (p == 2.0f) emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 0, FL, 0>(W); }); \
-                              else emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 0, FL, 1>(W); }); } while (0)
+                              else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APM_WAVES, [&] { ap_spec2048_run_kernel<PM, 0, FL, 1>(W); }); } while (0)
+    emu_lds_limit(W.lds_bytes);
     if (flatness) { if (power == 2.0f) EMU_SPEC(2, 1); else if (power == 1.0f) EMU_SPEC(1, 1); else EMU_SPEC(0, 1); }
     else { if (power == 2.0f) EMU_SPEC(2, 0); else if (power == 1.0f) EMU_SPEC(1, 0); else EMU_SPEC(0, 0); }
 #undef EMU_SPEC
@@ -477,6 +479,20 @@ int emu_spectral_audio_f32(const float *y, int64_t B, int64_t L, int hop, const 
 }
 
 int emu_cfft_split(int64_t N, int *N1, int *N2) { return ap_cfft_split(N, N1, N2); }
+
+// launches that wrote past the dynamic LDS their host code asked for (emu_shim.h), since the library was loaded
+int emu_lds_overrun_count() { return emu_lds_overruns; }
+
+// proves the guard sees an overrun: a launch that was promised 1024 bytes of LDS writes byte 2000; returns the
+// number of overruns it added (1) and takes it off the count again
+int emu_lds_guard_selftest() {
+    const int before = emu_lds_overruns;
+    emu_lds_limit(1024);
+    emu_launch(1, 64, [&] { if (threadIdx.x == 0) ap_smem[2000] = 1; });
+    const int seen = emu_lds_overruns - before;
+    emu_lds_overruns = before;
+    return seen;
+}
 
 int emu_pcg64_uniform_f32(unsigned long long st_hi, unsigned long long st_lo, unsigned long long inc_hi,
                           unsigned long long inc_lo, double low, double high, int64_t n, float *out) {

@@ -57,8 +57,19 @@ alignas(16) inline char ap_smem_storage[160 * 1024];
 // -> after the macros above that is an extern char array; define it here.
 extern char ap_smem[];
 
+// Dynamic-LDS guard: a launcher that knows the kernel's lds_bytes calls emu_lds_limit(bytes) first; everything
+// past that offset is poisoned for the launch and checked afterwards (a kernel writing beyond the LDS the host
+// asked for corrupts a neighbour or faults on the GPU; here it would go unnoticed inside the 160 KB array).
+inline int emu_lds_limit_bytes = 0;
+inline int emu_lds_overruns = 0;
+inline void emu_lds_limit(int bytes) { emu_lds_limit_bytes = bytes; }
+
 template <class F>
 void emu_launch(unsigned grid, unsigned block, F &&body) {
+    const int guard_from = emu_lds_limit_bytes;
+    emu_lds_limit_bytes = 0;
+    if (guard_from > 0)
+        for (int i = guard_from; i < 160 * 1024; ++i) ap_smem[i] = (char)0xA5;
     gridDim.x = grid;
     blockDim.x = block;
     std::barrier<> bar((std::ptrdiff_t)block);
@@ -83,4 +94,7 @@ void emu_launch(unsigned grid, unsigned block, F &&body) {
     }
     for (auto &th : threads) th.join();
     emu_barrier_ptr = nullptr;
+    if (guard_from > 0)
+        for (int i = guard_from; i < 160 * 1024; ++i)
+            if (ap_smem[i] != (char)0xA5) { ++emu_lds_overruns; break; }
 }

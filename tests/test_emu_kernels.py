@@ -480,3 +480,11 @@ def test_emu_frames8_index_remapped_edges(n_fft, hop, pad_mode, L, B):
     A, amax = eb.melspec(y, n_fft, hop, win, fb, pad_mode=PM[pad_mode], return_max=True)
     np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
     assert amax == A.max()                 # only the fused kernels hand the maximum back
+
+
+def test_zz_no_kernel_wrote_past_its_dynamic_lds():
+    """Runs last in this file: every emulated launch above poisoned the LDS beyond the lds_bytes its host code
+    computed and checked it afterwards (tests/emu/emu_shim.h)."""
+    assert eb.lds_overruns() == 0
+    assert eb.lib().emu_lds_guard_selftest() == 1          # the guard does see a write past the limit
+    assert eb.lds_overruns() == 0
