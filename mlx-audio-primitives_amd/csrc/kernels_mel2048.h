@@ -35,87 +35,7 @@
 #define APM_RUN 8             // frames per output run held in registers
 #define APM_PARTIAL_OFF 1152  // float offset of the partial sums inside the wave's X buffer (plane: 1025 floats)
 
-// per-lane constants of the transform (on top of ApwLane)
-struct ApmLane {
-    float c1, c2;        // stage coefficients of the quad radix-4: -s1, -s2
-    float sg;            // s1 s2: folded into the W_64^(a c) twiddles (and into v[0])
-    bool rot;            // lane 3 of the quad: multiply by -i between the stages
-};
-
-AP_DEV ApmLane apm_lane_init(int lane) {
-    ApmLane m;
-    const int qa = lane & 3;
-    const float s1 = qa < 2 ? 1.0f : -1.0f, s2 = (qa & 1) ? -1.0f : 1.0f;
-    m.c1 = -s1;
-    m.c2 = -s2;
-    m.sg = s1 * s2;
-    m.rot = qa == 3;
-    return m;
-}
-
-// Radix-4 across the quad on values held as h = (s1 s2) v, 8 complex values per call:
-//   stage 1: r = h - s1 h[lane ^ 2]         (= s2 (s1 v + v[lane ^ 2]))
-//   lane 3:  r *= -i                        (x, y) -> (y, -x)
-//   stage 2: out = r - s2 r[lane ^ 1]       (= s2 r' + r'[lane ^ 1] for the unsigned r')
-// outputs in bit-reversed lanes as in apw_forward.
-#ifdef AP_HOST_EMU
-AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
-    for (int i = 0; i < 8; ++i) {
-        v[i].x = v[i].x + m.c1 * ap_quad_xor2(v[i].x);
-        v[i].y = v[i].y + m.c1 * ap_quad_xor2(v[i].y);
-    }
-    for (int i = 0; i < 8; ++i) {
-        const float rx = v[i].x, ry = v[i].y;
-        v[i].x = m.rot ? ry : rx;
-        v[i].y = m.rot ? -rx : ry;
-    }
-    for (int i = 0; i < 8; ++i) {
-        v[i].x = v[i].x + m.c2 * ap_quad_xor1(v[i].x);
-        v[i].y = v[i].y + m.c2 * ap_quad_xor1(v[i].y);
-    }
-}
-#else
-// One asm block: v_fmac_f32_dpp takes the quad-permuted operand straight into the FMA
-// (d += c * d[lane ^ 2]); the compiler neither folds a DPP move into a VOP2 FMA here nor knows
-// about the DPP read inside an asm, so the block orders its instructions itself: `s_nop 1` covers
-// the 2 wait states between an outside VALU write and the first DPP read of that register, and
-// inside every DPP read sits >= 14 instructions behind the write of its register.  The halves of
-// the complex register pairs are named directly (v[i].x / v[i].y): no unpacking moves.
-// lane 3 of the quad: (x, y) -> (y, -x), written to a fresh register pair (operands nx, ny) that stage 2
-// carries on with: no copy of the old x, and the pair stays a pair for the packed code that follows.
-#define APM_ROT(ix, iy, nx, ny)                            \
-    "v_cndmask_b32 %" #nx ", %" #ix ", %" #iy ", %34\n\t"  \
-    "v_cndmask_b32 %" #ny ", %" #iy ", -%" #ix ", %34\n\t"
-#define APM_S2N(i) "v_fmac_f32_dpp %" #i ", %" #i ", %33 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-#define APM_S1N(i) "v_fmac_f32_dpp %" #i ", %" #i ", %32 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
-    ap_float2 n[8];
-    const unsigned long long rot_mask = 0x8888888888888888ull;      // lane 3 of every quad
-    asm volatile(
-        "s_nop 1\n\t"
-        APM_S1N(0) APM_S1N(1) APM_S1N(2) APM_S1N(3) APM_S1N(4) APM_S1N(5) APM_S1N(6) APM_S1N(7)
-        APM_S1N(8) APM_S1N(9) APM_S1N(10) APM_S1N(11) APM_S1N(12) APM_S1N(13) APM_S1N(14) APM_S1N(15)
-        APM_ROT(0, 1, 16, 17) APM_ROT(2, 3, 18, 19) APM_ROT(4, 5, 20, 21) APM_ROT(6, 7, 22, 23)
-        APM_ROT(8, 9, 24, 25) APM_ROT(10, 11, 26, 27) APM_ROT(12, 13, 28, 29) APM_ROT(14, 15, 30, 31)
-        APM_S2N(16) APM_S2N(17) APM_S2N(18) APM_S2N(19) APM_S2N(20) APM_S2N(21) APM_S2N(22) APM_S2N(23)
-        APM_S2N(24) APM_S2N(25) APM_S2N(26) APM_S2N(27) APM_S2N(28) APM_S2N(29) APM_S2N(30) APM_S2N(31)
-        : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
-          "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y),
-          "=&v"(n[0].x), "=&v"(n[0].y), "=&v"(n[1].x), "=&v"(n[1].y), "=&v"(n[2].x), "=&v"(n[2].y), "=&v"(n[3].x), "=&v"(n[3].y),
-          "=&v"(n[4].x), "=&v"(n[4].y), "=&v"(n[5].x), "=&v"(n[5].y), "=&v"(n[6].x), "=&v"(n[6].y), "=&v"(n[7].x), "=&v"(n[7].y)
-        : "v"(m.c1), "v"(m.c2), "s"(rot_mask));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = n[i];
-}
-#undef APM_S1N
-#undef APM_S2N
-#undef APM_ROT
-#endif
-
-AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
-    apm_quad8(&v[0], m);
-    apm_quad8(&v[8], m);
-}
+// (ApmLane, apm_quad8 / apm_quad_radix4: kernels_wave.h - the STFT and irfft kernels use them too)
 
 // Which frame-invariant per-lane tables stay in REGISTERS for the whole kernel instead of being
 // re-read from LDS every frame (bit mask; 8 waves per CU leave 256 VGPRs per lane).  The product
@@ -254,11 +174,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
                         reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid, nt);
     }
     AP_LDS_BARRIER();
-    if (tid < 64) {       // fold the quad stage's signs s1 s2 of row a = tid >> 4 into its twiddles
-        const int a = tid >> 4;
-        const float sg = (a == 1 || a == 2) ? -1.0f : 1.0f;
-        TW2[a * 17 + (tid & 15)] = ap_scale(TW2[a * 17 + (tid & 15)], sg);
-    }
+    // (apw_fill_tables has folded the quad stage's signs s1 s2 into the W_64 rows)
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     const ApmLane lm = apm_lane_init(lane);
     // per-lane tables kept in registers (REGS): straight from the global tables
@@ -549,11 +465,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_spec2048_run_kernel(ApSpec
     apw_fill_tables(TW2, reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
                     reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid, 64 * NW);
     AP_LDS_BARRIER();
-    if (tid < 64) {       // fold the quad stage's signs s1 s2 of row a = tid >> 4 into its twiddles
-        const int a = tid >> 4;
-        const float sg = (a == 1 || a == 2) ? -1.0f : 1.0f;
-        TW2[a * 17 + (tid & 15)] = ap_scale(TW2[a * 17 + (tid & 15)], sg);
-    }
+    // (apw_fill_tables has folded the quad stage's signs s1 s2 into the W_64 rows)
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     const ApmLane lm = apm_lane_init(lane);
     ap_float2 winr[16], t1r[16], t2r[16], wsp[8];

@@ -183,9 +183,95 @@ AP_DEV ApwLane apw_lane_init(int lane, const ap_float2 *TW2, const ap_float2 *tw
 // workgroup tables: W_64^(a*c) [4][17], W_1024^(lane*k1) [16][64], window as 1024 float pairs
 AP_DEV void apw_fill_tables(ap_float2 *tw2, ap_float2 *tw1, ap_float2 *win, const ap_float2 *tw,
                             const float *window, int tid, int nt) {
-    if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = tw[32 * (tid >> 4) * (tid & 15)];
+    // W_64^(a c) with the quad stage's per-lane signs s1 s2 of row a folded in (apm_quad8 works on (s1 s2) v)
+    if (tid < 64) {
+        const int a = tid >> 4;
+        tw2[a * 17 + (tid & 15)] = ap_scale(tw[32 * a * (tid & 15)], (a == 1 || a == 2) ? -1.0f : 1.0f);
+    }
     for (int i = tid; i < 16 * 64; i += nt) tw1[i] = tw[2 * (i & 63) * (i >> 6)];
     for (int i = tid; i < APW_NC; i += nt) win[i] = reinterpret_cast<const ap_float2 *>(window)[i];
+}
+
+// per-lane constants of the transform (on top of ApwLane)
+struct ApmLane {
+    float c1, c2;        // stage coefficients of the quad radix-4: -s1, -s2
+    float sg;            // s1 s2: folded into the W_64^(a c) twiddles (and into v[0])
+    bool rot;            // lane 3 of the quad: multiply by -i between the stages
+};
+
+AP_DEV ApmLane apm_lane_init(int lane) {
+    ApmLane m;
+    const int qa = lane & 3;
+    const float s1 = qa < 2 ? 1.0f : -1.0f, s2 = (qa & 1) ? -1.0f : 1.0f;
+    m.c1 = -s1;
+    m.c2 = -s2;
+    m.sg = s1 * s2;
+    m.rot = qa == 3;
+    return m;
+}
+
+// Radix-4 across the quad on values held as h = (s1 s2) v, 8 complex values per call:
+//   stage 1: r = h - s1 h[lane ^ 2]         (= s2 (s1 v + v[lane ^ 2]))
+//   lane 3:  r *= -i                        (x, y) -> (y, -x)
+//   stage 2: out = r - s2 r[lane ^ 1]       (= s2 r' + r'[lane ^ 1] for the unsigned r')
+// outputs in bit-reversed lanes as in apw_forward.
+#ifdef AP_HOST_EMU
+AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
+    for (int i = 0; i < 8; ++i) {
+        v[i].x = v[i].x + m.c1 * ap_quad_xor2(v[i].x);
+        v[i].y = v[i].y + m.c1 * ap_quad_xor2(v[i].y);
+    }
+    for (int i = 0; i < 8; ++i) {
+        const float rx = v[i].x, ry = v[i].y;
+        v[i].x = m.rot ? ry : rx;
+        v[i].y = m.rot ? -rx : ry;
+    }
+    for (int i = 0; i < 8; ++i) {
+        v[i].x = v[i].x + m.c2 * ap_quad_xor1(v[i].x);
+        v[i].y = v[i].y + m.c2 * ap_quad_xor1(v[i].y);
+    }
+}
+#else
+// One asm block: v_fmac_f32_dpp takes the quad-permuted operand straight into the FMA
+// (d += c * d[lane ^ 2]); the compiler neither folds a DPP move into a VOP2 FMA here nor knows
+// about the DPP read inside an asm, so the block orders its instructions itself: `s_nop 1` covers
+// the 2 wait states between an outside VALU write and the first DPP read of that register, and
+// inside every DPP read sits >= 14 instructions behind the write of its register.  The halves of
+// the complex register pairs are named directly (v[i].x / v[i].y): no unpacking moves.
+// lane 3 of the quad: (x, y) -> (y, -x), written to a fresh register pair (operands nx, ny) that stage 2
+// carries on with: no copy of the old x, and the pair stays a pair for the packed code that follows.
+#define APM_ROT(ix, iy, nx, ny)                            \
+    "v_cndmask_b32 %" #nx ", %" #ix ", %" #iy ", %34\n\t"  \
+    "v_cndmask_b32 %" #ny ", %" #iy ", -%" #ix ", %34\n\t"
+#define APM_S2N(i) "v_fmac_f32_dpp %" #i ", %" #i ", %33 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define APM_S1N(i) "v_fmac_f32_dpp %" #i ", %" #i ", %32 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+AP_DEV void apm_quad8(ap_float2 *v, const ApmLane &m) {
+    ap_float2 n[8];
+    const unsigned long long rot_mask = 0x8888888888888888ull;      // lane 3 of every quad
+    asm volatile(
+        "s_nop 1\n\t"
+        APM_S1N(0) APM_S1N(1) APM_S1N(2) APM_S1N(3) APM_S1N(4) APM_S1N(5) APM_S1N(6) APM_S1N(7)
+        APM_S1N(8) APM_S1N(9) APM_S1N(10) APM_S1N(11) APM_S1N(12) APM_S1N(13) APM_S1N(14) APM_S1N(15)
+        APM_ROT(0, 1, 16, 17) APM_ROT(2, 3, 18, 19) APM_ROT(4, 5, 20, 21) APM_ROT(6, 7, 22, 23)
+        APM_ROT(8, 9, 24, 25) APM_ROT(10, 11, 26, 27) APM_ROT(12, 13, 28, 29) APM_ROT(14, 15, 30, 31)
+        APM_S2N(16) APM_S2N(17) APM_S2N(18) APM_S2N(19) APM_S2N(20) APM_S2N(21) APM_S2N(22) APM_S2N(23)
+        APM_S2N(24) APM_S2N(25) APM_S2N(26) APM_S2N(27) APM_S2N(28) APM_S2N(29) APM_S2N(30) APM_S2N(31)
+        : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+          "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y),
+          "=&v"(n[0].x), "=&v"(n[0].y), "=&v"(n[1].x), "=&v"(n[1].y), "=&v"(n[2].x), "=&v"(n[2].y), "=&v"(n[3].x), "=&v"(n[3].y),
+          "=&v"(n[4].x), "=&v"(n[4].y), "=&v"(n[5].x), "=&v"(n[5].y), "=&v"(n[6].x), "=&v"(n[6].y), "=&v"(n[7].x), "=&v"(n[7].y)
+        : "v"(m.c1), "v"(m.c2), "s"(rot_mask));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = n[i];
+}
+#undef APM_S1N
+#undef APM_S2N
+#undef APM_ROT
+#endif
+
+AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
+    apm_quad8(&v[0], m);
+    apm_quad8(&v[8], m);
 }
 
 // windowed samples v[j] = z[lane + 64 j]  ->  Z[k] in natural order in the wave's X buffer
@@ -215,31 +301,12 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
     for (int cc = 1; cc < 16; ++cc) t2[cc] = c.tw2row[cc];         // W_64^(a*c)
     AP_WAVE_SYNC();
     ApButterfly<16>::run(v);
+    const ApmLane m = apm_lane_init(lane);
+    v[0] = ap_scale(v[0], m.sg);
 #pragma unroll
-    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);
-    // radix-4 across the quad (DIF), outputs in bit-reversed lanes.  Stage by stage over 8
-    // values at a time so that dependent instructions sit 8 apart (a DPP read of a fresh VALU
-    // result otherwise costs wait states).
-#pragma unroll
-    for (int h = 0; h < 16; h += 8) {
-        ap_float2 p[8];
-        AP_SCHED_FENCE();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = ap_mk(ap_quad_xor2(v[h + i].x), ap_quad_xor2(v[h + i].y));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[h + i] = ap_fma_s(v[h + i], c.s1, p[i]);
-        AP_SCHED_FENCE();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = ap_scale(v[h + i], c.rotw.x);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[h + i] = ap_cmul_tail_fw(v[h + i], c.rotw, p[i]);   // * (-i) on lane 3
-        AP_SCHED_FENCE();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = ap_mk(ap_quad_xor1(v[h + i].x), ap_quad_xor1(v[h + i].y));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[h + i] = ap_fma_s(v[h + i], c.s2, p[i]);
-        AP_SCHED_FENCE();
-    }
+    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);      // the table carries the signs s1 s2
+    // radix-4 across the quad (DIF) on v_fmac_f32_dpp, outputs in bit-reversed lanes
+    apm_quad_radix4(v, m);
     // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d (skipped when the caller stores
     // v[cc] = Z[k1p + 16 cc + 256 qd] itself)
     if (TO_LDS) {
@@ -718,7 +785,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_irfft2048_wave_kernel(Ap
     {
         ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
         ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
-        if (tid < 64) tw2[(tid >> 4) * 17 + (tid & 15)] = P.tw[32 * (tid >> 4) * (tid & 15)];
+        if (tid < 64)       // signs of the quad stage folded in, as in apw_fill_tables
+            tw2[(tid >> 4) * 17 + (tid & 15)] = ap_scale(P.tw[32 * (tid >> 4) * (tid & 15)], ((tid >> 4) == 1 || (tid >> 4) == 2) ? -1.0f : 1.0f);
         for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
         if (OLA) {
             float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
