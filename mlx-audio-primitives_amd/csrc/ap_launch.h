@@ -461,6 +461,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
                                          int *grid) {
     if (!(plan && desc && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
     if (!ap_clip_loads_ok(P)) return 1;
+    if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;          // 32-bit frame and sample arithmetic in the loop
     if (P.n_mels > 128) return 1;
     W.y = P.y;
     W.window = P.window;

@@ -17,6 +17,7 @@
 // Everything after the split - power, plan-based contraction, row sums - is the scheme of
 // kernels_wave.h.  Reference: mel.py:245-352 (stft.py:130 + mel.py:344-350).
 #pragma once
+#include <type_traits>
 #include "kernels_wave.h"
 
 #define APH_NC 512            // complex points
@@ -110,7 +111,10 @@ struct ApMelWave512Params {
     int off_tw1, off_tw2, off_win, off_wq, off_parts, off_partial, lds_bytes;
 };
 
-template <int PMODE>
+// HOPJ = 2: hop = 256, the next frame reuses 6 of this frame's 8 sample pairs per lane - with the loop trip of four
+// frames and one copy of the body per register rotation of kernels_mel2048.h (no copies); HOPJ = 0: any hop, every
+// frame loaded whole.  (clip, frame) advance incrementally; the 8-frame output run sits at static register positions.
+template <int PMODE, int HOPJ>
 __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMelWave512Params P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,62 +165,52 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
     const int64_t n_frames = P.n_clips * P.T;
     const int64_t f_lo = n_frames * worker / n_workers, f_hi = n_frames * (worker + 1) / n_workers;
     float vmax = -INFINITY;
-    ap_float2 raw[8];
-    auto load_frame = [&](int64_t f) {
-        const int64_t b = f / P.T;
-        const int64_t t = f - b * P.T;
-        const ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
-        const int64_t base = t * (int64_t)P.hop - P.pad;
+    if (f_lo < f_hi) {
+        int64_t b = f_lo / P.T;                   // the only division: (clip, frame) advance incrementally
+        int t = (int)(f_lo - b * P.T);
+        const int Ti = (int)P.T;
+        ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
+        constexpr int U = HOPJ == 2 ? 4 : 1;
+        ap_float2 raw[8];
+        auto load_frame = [&](int tt, auto rot_tag) {
+            constexpr int ROT = decltype(rot_tag)::value;
+            const int base = tt * P.hop - P.pad;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t p = base + 2 * (lane + 64 * j);
-            raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
-        }
-    };
-    // hop = 128 s: pair j of the next frame is pair j + s of this one (kernels_wave.h)
-    auto next_frame = [&](int64_t f) {
-        const int64_t b = f / P.T;
-        const int64_t t = f - b * P.T;
-        if (t == 0 || P.hopj == 0) { load_frame(f); return; }
-        const ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
-        const int64_t base = t * (int64_t)P.hop - P.pad;
-#define APH_SHIFT_LOAD(S)                                                                    \
-        {                                                                                    \
-            _Pragma("unroll") for (int j = 0; j < 8 - (S); ++j) raw[j] = raw[j + (S)];       \
-            _Pragma("unroll") for (int j = 8 - (S); j < 8; ++j) {                             \
-                const int64_t p = base + 2 * (lane + 64 * j);                                \
-                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));            \
-            }                                                                                \
-        }
-        if (P.hopj == 2) APH_SHIFT_LOAD(2)
-        else if (P.hopj == 1) APH_SHIFT_LOAD(1)
-        else APH_SHIFT_LOAD(4)
-#undef APH_SHIFT_LOAD
-    };
-    if (f_lo < f_hi) load_frame(f_lo);
-
-    for (int64_t f = f_lo; f < f_hi;) {
-        const int64_t b = f / P.T;
-        const int64_t t0 = f - b * P.T;
-        int64_t run = P.T - t0;
-        if (run > 8) run = 8;
-        if (run > f_hi - f) run = f_hi - f;
-        const int Gt = (int)run;
-        float acc0[8], acc1[8];          // the run's values of rows lane and lane + 64 (newest last)
+            for (int j = 0; j < 8; ++j) raw[(j + HOPJ * ROT) & 7] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+        };
+        load_frame(t, std::integral_constant<int, 0>());
+        float acc0[8], acc1[8];                   // the run's values of rows lane and lane + 64
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+        int nrun = 0, half = 0;
+        int64_t f = f_lo;
 
-        for (int g = 0; g < Gt; ++g) {
+        auto frame = [&](auto rot_tag) -> bool {
+            constexpr int ROT = decltype(rot_tag)::value;
+            constexpr int NROT = (ROT + 1) % U;
             ap_float2 v[8];
             {
                 ap_float2 w[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) w[j] = WIN[lane + 64 * j];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ap_mul2(raw[j], w[j]);
+                for (int j = 0; j < 8; ++j) v[j] = ap_mul2(raw[(j + HOPJ * ROT) & 7], w[j]);
             }
+            const bool clip_ends = t + 1 == Ti;
+            const bool more = f + 1 < f_hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) AP_PIN(v[j]);         // the samples' registers are free for the prefetch
             AP_SCHED_FENCE();
-            if (f + g + 1 < f_hi) next_frame(f + g + 1);
+            if (more) {
+                if (clip_ends) clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
+                const int base = (clip_ends ? 0 : t + 1) * P.hop - P.pad;
+#pragma unroll
+                for (int j = 8 - HOPJ; j < 8; ++j) raw[(j + HOPJ * NROT) & 7] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+                if (HOPJ == 0 || clip_ends) {
+#pragma unroll
+                    for (int j = 0; j < 8 - HOPJ; ++j) raw[(j + HOPJ * NROT) & 7] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+                }
+            }
             AP_SCHED_FENCE();
             aph_forward(v, X, TW1, TW2, lane);
             {
@@ -273,7 +267,7 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
                 partial[pd.z < 0 ? P.n_slots : pd.z] = acc[1];
             }
             AP_WAVE_SYNC();
-            // ---- row sums into the run's registers (shift: newest value last) -------------------
+            // ---- row sums into the run's registers ---------------------------------------------------
             float sum2[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -289,36 +283,61 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
                 sum2[i] = sum;
                 if (lane + 64 * i < M) vmax = fmaxf(vmax, sum);
             }
+            // the frame's position in the run registers (kernels_mel2048.h)
+            int pos;
+            if (U == 1) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { acc0[i] = acc0[i + 1]; acc1[i] = acc1[i + 1]; }
-            acc0[7] = sum2[0];
-            acc1[7] = sum2[1];
+                for (int i = 0; i < 7; ++i) { acc0[i] = acc0[i + 1]; acc1[i] = acc1[i + 1]; }
+                acc0[7] = sum2[0];
+                acc1[7] = sum2[1];
+                pos = 7;
+            } else {
+                if (half) { acc0[4 + ROT] = sum2[0]; acc1[4 + ROT] = sum2[1]; }
+                else { acc0[ROT] = sum2[0]; acc1[ROT] = sum2[1]; }
+                pos = 4 * half + ROT;
+            }
+            ++nrun;
             AP_WAVE_SYNC();
-        }
-        // ---- store the run: frame t0 + g sits in register 8 - Gt + g ------------------------------
-        {
-            float *ob = P.out + b * (int64_t)M * P.T + t0;
+            // ---- store the run when it is full, the clip ends or the stretch ends ---------------------
+            if ((U == 1 ? nrun == 8 : pos == 7) || clip_ends || !more) {
+                const int first = pos - nrun + 1;
+                float *ob = P.out + b * (int64_t)M * P.T + (t - nrun + 1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = lane + 64 * i;
-                if (row < M) {
-                    float *dst = ob + (int64_t)row * P.T;
-                    const float *src = i == 0 ? acc0 : acc1;
-                    if (Gt == 8) {               // 32 contiguous bytes: two 16-byte stores (4-byte aligned)
-                        ap_rsp_f4u lo, hi;
-                        lo.x = src[0]; lo.y = src[1]; lo.z = src[2]; lo.w = src[3];
-                        hi.x = src[4]; hi.y = src[5]; hi.z = src[6]; hi.w = src[7];
-                        *reinterpret_cast<ap_rsp_f4u *>(dst) = lo;
-                        *reinterpret_cast<ap_rsp_f4u *>(dst + 4) = hi;
-                    } else {
+                for (int i = 0; i < 2; ++i) {
+                    const int row = lane + 64 * i;
+                    if (row < M) {
+                        float *dst = ob + (int64_t)row * P.T;
+                        const float *src = i == 0 ? acc0 : acc1;
+                        if (nrun == 8) {            // 32 contiguous bytes: two 16-byte stores (4-byte aligned)
+                            ap_rsp_f4u lo, hi;
+                            lo.x = src[0]; lo.y = src[1]; lo.z = src[2]; lo.w = src[3];
+                            hi.x = src[4]; hi.y = src[5]; hi.z = src[6]; hi.w = src[7];
+                            *reinterpret_cast<ap_rsp_f4u *>(dst) = lo;
+                            *reinterpret_cast<ap_rsp_f4u *>(dst + 4) = hi;
+                        } else {
 #pragma unroll
-                        for (int g = 0; g < 8; ++g)
-                            if (g >= 8 - Gt) dst[g - (8 - Gt)] = src[g];
+                            for (int g = 0; g < 8; ++g)
+                                if (g >= first && g <= pos) dst[g - first] = src[g];
+                        }
                     }
                 }
+                nrun = 0;
+            }
+            if (clip_ends) { t = 0; ++b; } else { ++t; }
+            ++f;
+            return more;
+        };
+        if (U == 1) {
+            while (frame(std::integral_constant<int, 0>())) {}
+        } else {
+            for (;;) {
+                if (!frame(std::integral_constant<int, 0>())) break;
+                if (!frame(std::integral_constant<int, 1 % U>())) break;
+                if (!frame(std::integral_constant<int, 2 % U>())) break;
+                if (!frame(std::integral_constant<int, 3 % U>())) break;
+                half ^= 1;
             }
         }
-        f += Gt;
     }
     if (P.max_key) {
         AP_WAVE_SYNC();

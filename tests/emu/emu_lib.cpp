@@ -215,9 +215,16 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
         if (ap_prepare_mel_wave512(W, P, B, plan, desc, APH_WAVES, APH_X_COMPLEX, APH_PASSES, &grid) == AP_OK) {
             if (grid > 1) grid = 1;   // exercise the persistent frame loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
-            if (power == 2.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2>(W); });
-            else if (power == 1.0f) emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1>(W); });
-            else emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0>(W); });
+            emu_lds_limit(W.lds_bytes);
+            if (hop == 256) {
+                if (power == 2.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2, 2>(W); });
+                else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1, 2>(W); });
+                else emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0, 2>(W); });
+            } else {
+                if (power == 2.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2, 0>(W); });
+                else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1, 0>(W); });
+                else emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0, 0>(W); });
+            }
             return AP_OK;
         }
     }
