@@ -225,3 +225,24 @@ def test_mfcc_clip_sharded_with_reduced_key_equals_unsharded():
     # world size 1: group=True is a no-op
     assert torch.equal(ap.mfcc(yd, group=True, **kw), full)
     np.testing.assert_allclose(host(full), ao.mfcc(y, **kw), rtol=1e-4, atol=2e-3)
+
+
+def test_ops_follow_their_tensors_device():
+    """every launch must run on the device of its tensors, not on torch's current device.  Needs
+    two GPUs (skipped on the one-GPU boxes); on a multi-GPU node the call below runs on cuda:1 while the
+    current device stays cuda:0."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((4, 30000)).astype(np.float32)
+    kw = dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    want = ao.melspectrogram(y, **kw)
+    with torch.cuda.device(0):
+        y1 = torch.from_numpy(y).to("cuda:1")
+        S1 = ap.melspectrogram(y1, **kw)
+        assert S1.device == torch.device("cuda:1") and torch.cuda.current_device() == 0
+        np.testing.assert_allclose(S1.cpu().numpy(), want, rtol=1e-4, atol=1e-3)
+        m1 = ap.mfcc(y1, n_mfcc=13, **kw)
+        z1 = ap.istft(ap.stft(y1), hop_length=512, length=30000)
+        np.testing.assert_allclose(z1.cpu().numpy(), y, atol=1e-5)
+        np.testing.assert_allclose(m1.cpu().numpy(), ao.mfcc(y, n_mfcc=13, **kw), rtol=1e-3, atol=2e-3)
