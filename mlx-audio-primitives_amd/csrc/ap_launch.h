@@ -460,7 +460,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
                                          const int32_t *desc, int n_waves, int x_complex, int passes_reg,
                                          int *grid) {
     if (!(plan && desc && (desc[0] & AP_PLAN_PARTS)) || (desc[0] & AP_PLAN_FORCE_GENERIC)) return 1;
-    if (!ap_clip_loads_ok(P)) return 1;
+    // (reflect / edge padding, odd hops: the caller launches the PADGEN instantiation)
     if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;          // 32-bit frame and sample arithmetic in the loop
     if (P.n_mels > 128) return 1;
     W.y = P.y;
@@ -482,6 +482,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
     W.n_clips = B;
     W.hop = P.hop;
     W.pad = P.pad;
+    W.pad_mode = P.pad_mode;
     W.n_mels = P.n_mels;
     W.power = P.power;
     W.hopj = (P.hop == 128 || P.hop == 256 || P.hop == 512) ? P.hop / 128 : 0;

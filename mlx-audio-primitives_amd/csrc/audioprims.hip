@@ -359,11 +359,13 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
                 if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
                 W.max_key = max_key_dev;
             }
-            // hop = 256: the next frame reuses three quarters of this frame's samples in registers
-            auto kern = hop == 256 ? (power == 2.0f ? ap_mel1024_wave_kernel<2, 2> : power == 1.0f ? ap_mel1024_wave_kernel<1, 2>
-                                                                                                    : ap_mel1024_wave_kernel<0, 2>)
-                                   : (power == 2.0f ? ap_mel1024_wave_kernel<2, 0> : power == 1.0f ? ap_mel1024_wave_kernel<1, 0>
-                                                                                                    : ap_mel1024_wave_kernel<0, 0>);
+            // hop = 256: the next frame reuses three quarters of this frame's samples in registers;
+            // reflect / edge padding and odd hops: index-remapped loads for the frames at the clip ends
+            const bool padgen = !ap_clip_loads_ok(P);
+#define AP_M1024(PM) (hop == 256 ? (padgen ? ap_mel1024_wave_kernel<PM, 2, 1> : ap_mel1024_wave_kernel<PM, 2, 0>) \
+                                 : (padgen ? ap_mel1024_wave_kernel<PM, 0, 1> : ap_mel1024_wave_kernel<PM, 0, 0>))
+            auto kern = power == 2.0f ? AP_M1024(2) : power == 1.0f ? AP_M1024(1) : AP_M1024(0);
+#undef AP_M1024
             rc = ap_allow_lds(kern, W.lds_bytes);
             if (rc != AP_OK) return rc;
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APH_WAVES), W.lds_bytes, (hipStream_t)stream, W);

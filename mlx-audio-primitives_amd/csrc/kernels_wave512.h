@@ -106,7 +106,7 @@ struct ApMelWave512Params {
     float *out;                // (B, M, T)
     unsigned *max_key;
     int64_t L, T, n_clips;
-    int hop, pad, n_mels, n_parts, n_quads, n_slots, max_row_parts, partial_stride, hopj;
+    int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots, max_row_parts, partial_stride, hopj;
     float power;
     int off_tw1, off_tw2, off_win, off_wq, off_parts, off_partial, lds_bytes;
 };
@@ -114,7 +114,8 @@ struct ApMelWave512Params {
 // HOPJ = 2: hop = 256, the next frame reuses 6 of this frame's 8 sample pairs per lane - with the loop trip of four
 // frames and one copy of the body per register rotation of kernels_mel2048.h (no copies); HOPJ = 0: any hop, every
 // frame loaded whole.  (clip, frame) advance incrementally; the 8-frame output run sits at static register positions.
-template <int PMODE, int HOPJ>
+// PADGEN: reflect / edge padding and odd hops - frames that reach over a clip end load through the index remap.
+template <int PMODE, int HOPJ, int PADGEN = 0>
 __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMelWave512Params P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,11 +173,18 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
         ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
         constexpr int U = HOPJ == 2 ? 4 : 1;
         ap_float2 raw[8];
+        auto ld2 = [&](int64_t bb, int base, int p) -> ap_float2 {
+            if (PADGEN && !(base >= 0 && (int64_t)base + 2 * APH_NC <= P.L)) {
+                const float *yb = P.y + bb * P.L;
+                return ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            }
+            return ap_clip_load2(clip, p);
+        };
         auto load_frame = [&](int tt, auto rot_tag) {
             constexpr int ROT = decltype(rot_tag)::value;
             const int base = tt * P.hop - P.pad;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) raw[(j + HOPJ * ROT) & 7] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+            for (int j = 0; j < 8; ++j) raw[(j + HOPJ * ROT) & 7] = ld2(b, base, base + 2 * (lane + 64 * j));
         };
         load_frame(t, std::integral_constant<int, 0>());
         float acc0[8], acc1[8];                   // the run's values of rows lane and lane + 64
@@ -205,10 +213,11 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
                 if (clip_ends) clip = ap_clip_make(P.y + (b + 1) * P.L, P.L);
                 const int base = (clip_ends ? 0 : t + 1) * P.hop - P.pad;
 #pragma unroll
-                for (int j = 8 - HOPJ; j < 8; ++j) raw[(j + HOPJ * NROT) & 7] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+                for (int j = 8 - HOPJ; j < 8; ++j) raw[(j + HOPJ * NROT) & 7] = ld2(clip_ends ? b + 1 : b, base, base + 2 * (lane + 64 * j));
                 if (HOPJ == 0 || clip_ends) {
 #pragma unroll
-                    for (int j = 0; j < 8 - HOPJ; ++j) raw[(j + HOPJ * NROT) & 7] = ap_clip_load2(clip, base + 2 * (lane + 64 * j));
+                    for (int j = 0; j < 8 - HOPJ; ++j)
+                        raw[(j + HOPJ * NROT) & 7] = ld2(clip_ends ? b + 1 : b, base, base + 2 * (lane + 64 * j));
                 }
             }
             AP_SCHED_FENCE();

@@ -216,15 +216,13 @@ int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, co
             if (grid > 1) grid = 1;   // exercise the persistent frame loop
             if (max_key) { *max_key = 0x007FFFFFu; W.max_key = max_key; }
             emu_lds_limit(W.lds_bytes);
-            if (hop == 256) {
-                if (power == 2.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2, 2>(W); });
-                else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1, 2>(W); });
-                else emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0, 2>(W); });
-            } else {
-                if (power == 2.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<2, 0>(W); });
-                else if (power == 1.0f) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<1, 0>(W); });
-                else emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<0, 0>(W); });
-            }
+            const bool padgen = !ap_clip_loads_ok(P);
+#define EMU_M1024(PM) do { if (hop == 256 && !padgen) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<PM, 2, 0>(W); }); \
+                           else if (hop == 256) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<PM, 2, 1>(W); }); \
+                           else if (!padgen) emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<PM, 0, 0>(W); }); \
+                           else emu_launch((unsigned)grid, 64 * APH_WAVES, [&] { ap_mel1024_wave_kernel<PM, 0, 1>(W); }); } while (0)
+            if (power == 2.0f) EMU_M1024(2); else if (power == 1.0f) EMU_M1024(1); else EMU_M1024(0);
+#undef EMU_M1024
             return AP_OK;
         }
     }

@@ -488,3 +488,17 @@ def test_zz_no_kernel_wrote_past_its_dynamic_lds():
     assert eb.lds_overruns() == 0
     assert eb.lib().emu_lds_guard_selftest() == 1          # the guard does see a write past the limit
     assert eb.lds_overruns() == 0
+
+
+@pytest.mark.parametrize("hop,pad_mode,L,B", [(256, "reflect", 6000, 2), (256, "edge", 3001, 3), (255, "constant", 4000, 2),
+                                              (300, "reflect", 5000, 1)])
+def test_emu_mel1024_index_remapped_edges(hop, pad_mode, L, B):
+    """PADGEN instantiation of the n_fft = 1024 mel kernel: reflect / edge padding, centred frames at odd hops."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 1024, 1024)
+    fb = ao.mel_filterbank(22050, 1024, 80)
+    R = ao.melspectrogram(y, sr=22050, n_fft=1024, hop_length=hop, n_mels=80, pad_mode=pad_mode)
+    A, amax = eb.melspec(y, 1024, hop, win, fb, pad_mode=PM[pad_mode], return_max=True)
+    np.testing.assert_allclose(A, R, rtol=1e-4, atol=1e-4)
+    assert amax == A.max()                 # only the fused kernels hand the maximum back

@@ -151,7 +151,8 @@ def test_istft_frames8_no_centre_and_fallback_hops():
 
 
 @pytest.mark.parametrize("pad_mode", ["reflect", "edge"])
-@pytest.mark.parametrize("n_fft,hop,B,L", [(512, 128, 3, 9001), (400, 160, 200, 4000), (256, 64, 2, 3000), (2048, 512, 3, 30001)])
+@pytest.mark.parametrize("n_fft,hop,B,L", [(512, 128, 3, 9001), (400, 160, 200, 4000), (256, 64, 2, 3000), (2048, 512, 3, 30001),
+                                           (1024, 256, 3, 20001)])
 def test_stft_and_mel_pad_modes_on_the_wave_kernels(pad_mode, n_fft, hop, B, L):
     """reflect / edge padding on the eight-frames-per-wave kernels and the n_fft = 2048 run kernel: only the
     frames that reach over a clip end take the index remap."""
