@@ -507,7 +507,6 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
 template <class W512>
 static inline int ap_prepare_stft_wave512(W512 &W, const ApStftParams &P, int64_t B, int n_waves,
                                           int x_complex, int ob_complex, int *grid) {
-    if (!ap_clip_loads_ok(P)) return 1;
     if (P.T > (1 << 20)) return 1;                        // 32-bit row offsets in the store phase
     W.y = P.y;
     W.window = P.window;
@@ -518,6 +517,8 @@ static inline int ap_prepare_stft_wave512(W512 &W, const ApStftParams &P, int64_
     W.groups_per_clip = (P.T + n_waves - 1) / n_waves;
     W.n_groups = W.groups_per_clip * B;
     W.hop = P.hop;
+    W.pad_mode = P.pad_mode;
+    W.padgen = ap_clip_loads_ok(P) ? 0 : 1;
     W.pad = P.pad;
     int off = n_waves * x_complex * (int)sizeof(ap_float2);
     W.off_tw1 = off; off += 8 * 64 * (int)sizeof(ap_float2);

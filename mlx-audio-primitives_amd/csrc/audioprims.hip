@@ -262,10 +262,10 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
         ApStftWave512Params W;
         int grid = 0;
         if (ap_prepare_stft_wave512(W, P, B, APHS_WAVES, APH_X_COMPLEX, APHS_OB_ROWS * APHS_OB_ROW, &grid) == AP_OK) {
-            rc = ap_allow_lds(ap_stft1024_wave_kernel, W.lds_bytes);
+            auto kern = W.padgen ? ap_stft1024_wave_kernel<1> : ap_stft1024_wave_kernel<0>;
+            rc = ap_allow_lds(kern, W.lds_bytes);
             if (rc != AP_OK) return rc;
-            hipLaunchKernelGGL(ap_stft1024_wave_kernel, dim3(grid), dim3(64 * APHS_WAVES), W.lds_bytes,
-                               (hipStream_t)stream, W);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APHS_WAVES), W.lds_bytes, (hipStream_t)stream, W);
             return ap_check_launch("ap_stft_f32(wave512)");
         }
     }

@@ -377,10 +377,11 @@ struct ApStftWave512Params {
     const ap_float2 *tw;       // (1024)
     ap_float2 *out;            // (B, 513, T)
     int64_t L, T, groups_per_clip, n_groups;
-    int hop, pad;
+    int hop, pad, pad_mode, padgen;   // padgen: reflect / edge padding or odd hops - index remap for the frames at the clip ends
     int off_tw1, off_tw2, off_win, off_ob, lds_bytes;
 };
 
+template <int PADGEN>
 __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(ApStftWave512Params P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -417,6 +418,15 @@ __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(Ap
         const ApClip clip = ap_clip_make(P.y + b * P.L, P.L);
         const int64_t base = t * (int64_t)P.hop - P.pad;
         // frames beyond T read past the clip: zeros (never stored)
+        if (PADGEN && t < P.T && !(base >= 0 && base + 2 * APH_NC <= P.L)) {
+            const float *yb = P.y + b * P.L;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
+                raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t p = base + 2 * (lane + 64 * j);

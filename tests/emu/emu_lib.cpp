@@ -148,7 +148,7 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
         int grid = 0;
         if (ap_prepare_stft_wave512(W, P, B, APHS_WAVES, APH_X_COMPLEX, APHS_OB_ROWS * APHS_OB_ROW, &grid) == AP_OK) {
             if (grid > 2) grid = 2;   // exercise the persistent group loop and the carries
-            emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_stft1024_wave_kernel(W); });
+            emu_lds_limit(W.lds_bytes), (W.padgen ? emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_stft1024_wave_kernel<1>(W); }) : emu_launch((unsigned)grid, 64 * APHS_WAVES, [&] { ap_stft1024_wave_kernel<0>(W); }));
             return AP_OK;
         }
     }

@@ -27,6 +27,8 @@ STFT_CASES = [
     # n_fft = 1024 wave kernel: 3 clips x 22 frames (carries, clip change in a stretch), no centring
     (1024, 256, 5376, 3, "constant", True),
     (1024, 300, 6100, 2, "constant", False),
+    (1024, 256, 4000, 2, "reflect", True),       # index-remapped edge frames in the wave kernel
+    (1024, 255, 3000, 1, "constant", True),      # centred frames at an odd hop
     (400, 160, 3000, 3, "constant", True),
     (64, 16, 500, 1, "edge", True),
     (30, 7, 400, 2, "constant", False),
