@@ -984,6 +984,14 @@ int ap_savgol_f32(const float *x, int64_t outer, int64_t n, int64_t inner, const
     if (outer <= 0 || n <= 0 || inner <= 0) AP_FAIL(AP_ERR_INVALID, "delta: empty array");
     if (mode == AP_SG_INTERP && (!edge || width > n))
         AP_FAIL(AP_ERR_INVALID, "when mode='interp', width=%d cannot exceed data.shape[axis]=%lld", width, (long long)n);
+    if (inner == 1 && width <= 64 && n < (1 << 30)) {       // contiguous axis: one row chunk per workgroup
+        const int64_t chunks = (n + AP_BLOCK * APSG_PER - 1) / (AP_BLOCK * APSG_PER);
+        if (outer * chunks <= kApMaxGrid) {
+            hipLaunchKernelGGL(ap_savgol_rows_kernel, dim3((unsigned)(outer * chunks)), dim3(AP_BLOCK), 0, (hipStream_t)stream,
+                               x, outer, (int)n, (int)chunks, taps, width, mode, cval, edge, out);
+            return ap_check_launch("ap_savgol_f32(rows)");
+        }
+    }
     hipLaunchKernelGGL(ap_savgol_kernel, dim3(ap_grid_1d(outer * n * inner, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
                        (hipStream_t)stream, x, outer, n, inner, taps, width, mode, cval, edge, out);
     return ap_check_launch("ap_savgol_f32");

@@ -509,6 +509,60 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_pcm16_to_f32_kernel(const int16_t
         out[e] = (float)x[e] * scale;
 }
 
+// The same along a contiguous axis (inner == 1: delta over time, the default axis = -1): a workgroup owns
+// 1024 consecutive positions of one row (4 per thread), the taps sit in LDS, positions whose window lies
+// inside the row take the plain FIR; the few at the row's ends go through the boundary rules above.  One
+// 32-bit division per workgroup instead of two 64-bit ones per element.
+#define APSG_PER 4
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_savgol_rows_kernel(const float *x, int64_t rows, int n, int chunks, const float *taps, int width, int mode, float cval,
+                      const float *edge, float *out) {
+    __shared__ float tp[64];
+    const int half = width / 2;
+    if (threadIdx.x < width) tp[threadIdx.x] = taps[threadIdx.x];
+    __syncthreads();
+    const int64_t row = blockIdx.x / chunks;
+    const int i0 = (int)(blockIdx.x - row * chunks) * (AP_BLOCK * APSG_PER);
+    const float *xb = x + row * n;
+    float *ob = out + row * n;
+#pragma unroll
+    for (int u = 0; u < APSG_PER; ++u) {
+        const int i = i0 + u * AP_BLOCK + threadIdx.x;
+        if (i >= n) break;
+        float acc = 0.0f;
+        if (i >= half && i < n - half) {
+            const float *w = xb + i - half;
+            for (int j = 0; j < width; ++j) acc = fmaf(tp[j], w[j], acc);
+        } else if (mode == AP_SG_INTERP) {
+            const bool head = i < half;
+            const float *rw = edge + (head ? i : half + (i - (n - half))) * width;
+            const int first = head ? 0 : n - width;
+            for (int j = 0; j < width; ++j) acc = fmaf(rw[j], xb[first + j], acc);
+        } else {
+            for (int j = 0; j < width; ++j) {
+                int q = i + j - half;
+                float v;
+                if (q >= 0 && q < n) v = xb[q];
+                else if (mode == AP_SG_CONSTANT) v = cval;
+                else {
+                    if (mode == AP_SG_NEAREST) q = q < 0 ? 0 : n - 1;
+                    else if (mode == AP_SG_MIRROR) {
+                        if (n == 1) q = 0;
+                        else {
+                            const int period = 2 * (n - 1);
+                            q = ((q % period) + period) % period;
+                            if (q >= n) q = period - q;
+                        }
+                    } else q = ((q % n) + n) % n;
+                    v = xb[q];
+                }
+                acc = fmaf(tp[j], v, acc);
+            }
+        }
+        ob[i] = acc;
+    }
+}
+
 // Signal extension of scipy.signal.upfirdn (the `mode` of scipy.signal.resample_poly's padtype, which the
 // reference passes through at resample.py:279-281): out (B, L + 2 P) = P extension samples, the signal, P
 // extension samples.  Every branch restates SciPy's _extend_left / _extend_right (third-party:
