@@ -251,7 +251,8 @@ static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, 
                                      const int32_t *desc, int n_waves, int x_complex, int partial_off,
                                      int *n_pass, int *grid) {
     // (reflect / edge padding and odd hops: the caller picks the kernel's index-remapping input mode)
-    if (P.n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 1;
+    if (P.n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 1;   // (rows of more than 4 parts: the tile kernel; a loop for them
+                                                                      // in the run kernel cost the headline shape 6 VGPRs and ~2 %)
     if (P.T > (1 << 24) || P.L > (1 << 28)) return 1;          // 32-bit frame and sample arithmetic in the loop
     W.y = P.y;
     W.window = P.window;

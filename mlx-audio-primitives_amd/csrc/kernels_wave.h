@@ -116,8 +116,13 @@ AP_DEV ApClip ap_clip_make(const float *base, int64_t n) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(n * 4), 0x00020000);
 }
 AP_DEV float ap_clip_load(ApClip c, int64_t idx) {
-    // a negative index wraps to a huge unsigned byte offset: out of range -> 0
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c, (int)(idx * 4), 0, 0));
+    // a negative index wraps to a huge unsigned byte offset: out of range -> 0.  The offset is made opaque:
+    // left alone the compiler splits it into a register part and an instruction immediate, and a 4-byte
+    // load whose register part is negative and whose sum is 0 or 4 comes back as 0 (measured: the first
+    // two samples of a clip were lost; the 8-byte loads are not affected)
+    int off = (int)(idx * 4);
+    AP_PIN(off);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(c, off, 0, 0));
 }
 // samples idx, idx + 1 as one 8-byte load.  idx must be even or the clip start must not fall inside a
 // pair: the pair (-1, 0) has a wrapped byte offset and reads as (0, 0), losing sample 0 (measured; the
@@ -148,7 +153,9 @@ AP_DEV ApClip16 ap_clip16_make(const int16_t *base, int64_t n) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<int16_t *>(base), 0, (int)(n * 2), 0x00020000);
 }
 AP_DEV ap_float2 ap_clip16_load2(ApClip16 c, int idx) {
-    const int d = __builtin_amdgcn_raw_buffer_load_b32(c, idx * 2, 0, 0);
+    int off = idx * 2;
+    AP_PIN(off);                         // no immediate part: see ap_clip_load
+    const int d = __builtin_amdgcn_raw_buffer_load_b32(c, off, 0, 0);
     return ap_mk((float)(short)(d & 0xFFFF), (float)(d >> 16));
 }
 #endif

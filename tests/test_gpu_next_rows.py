@@ -31,6 +31,7 @@ def _pcm(shape, seed):
     dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128),                    # fused into the run kernel
     dict(sr=16000, n_fft=2048, hop_length=512, n_mels=80, center=False),       # fused, no centring
     dict(sr=22050, n_fft=2048, hop_length=300, n_mels=64),                     # fused, full reload per frame
+    dict(sr=22050, n_fft=2048, hop_length=300, n_mels=128),                    # fused; a stretch starts on a frame that straddles sample 0
     dict(sr=16000, n_fft=400, hop_length=160, n_mels=80),                      # conversion pass + ct engine
     dict(sr=22050, n_fft=2048, hop_length=512, n_mels=128, pad_mode="reflect"),  # conversion pass + tile kernel
     dict(sr=22050, n_fft=1024, hop_length=256, n_mels=64, power=1.0),
@@ -214,3 +215,17 @@ def test_resample_poly_padtype_errors_and_short_signals():
     for padtype in _EXT:                  # the extension is many signal lengths deep
         want = scipy.signal.resample_poly(x, 3, 2, axis=-1, padtype=padtype).astype(np.float32)
         np.testing.assert_array_equal(host(ap.resample_poly(dev(x), 3, 2, padtype=padtype)), want)
+
+
+@pytest.mark.parametrize("B", [5, 7, 16])
+def test_int16_first_samples_of_a_clip_at_a_stretch_start(B):
+    """Regression: 4-byte bounds-checked loads whose offset the compiler had split into a negative register
+    part and an instruction immediate summing to 0 or 4 came back as 0, so the frame a wave STARTS its
+    stretch with lost the first two samples of its clip (only when that frame straddles sample 0)."""
+    x = np.zeros((B, 30000), np.int16)
+    x[:, 0] = 10000                                # an impulse on the very first sample of every clip
+    x[:, 2] = -7000
+    kw = dict(sr=22050, n_fft=2048, hop_length=300, n_mels=128)
+    got = host(ap.melspectrogram(dev(x), **kw))
+    want = ao.melspectrogram(x.astype(np.float32) / 32768.0, **kw)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-7)
