@@ -229,3 +229,22 @@ def test_int16_first_samples_of_a_clip_at_a_stretch_start(B):
     got = host(ap.melspectrogram(dev(x), **kw))
     want = ao.melspectrogram(x.astype(np.float32) / 32768.0, **kw)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(2048, 512, 128), (2048, 300, 128), (2048, 256, 80), (1024, 256, 80), (1024, 200, 64),
+                                              (512, 128, 64), (512, 100, 40), (400, 160, 80), (400, 100, 80), (256, 64, 32)])
+@pytest.mark.parametrize("B", [7, 64])
+def test_first_and_last_samples_of_every_clip_reach_their_frames(n_fft, hop, n_mels, B):
+    """Impulses on the first three and the last three samples of every clip: every frame that overlaps a clip end
+    must see them (bounds-checked loads with negative register offsets, prefetches that cross clip boundaries,
+    stretches that start on such frames)."""
+    L = 12000
+    x = np.zeros((B, L), np.float32)
+    x[:, 0], x[:, 1], x[:, 2] = 1.0, -0.7, 0.5
+    x[:, -1], x[:, -2], x[:, -3] = 0.9, -0.6, 0.4
+    kw = dict(sr=16000, n_fft=n_fft, hop_length=hop, n_mels=n_mels)
+    got = host(ap.melspectrogram(dev(x), **kw))
+    want = ao.melspectrogram(x[:1], **kw)
+    np.testing.assert_allclose(got, np.broadcast_to(want, got.shape), rtol=1e-4, atol=1e-7)
+    S = host(ap.stft(dev(x), n_fft=n_fft, hop_length=hop))
+    np.testing.assert_allclose(S, np.broadcast_to(ao.stft(x[0], n_fft=n_fft, hop_length=hop), S.shape), rtol=1e-4, atol=1e-6)
