@@ -198,6 +198,7 @@ static inline bool ap_mel_wave_eligible(int n_fft, const int32_t *plan, const in
 
 static inline int ap_prepare_mel_wave(ApMelWaveParams &W, const ApStftParams &P, int64_t B,
                                       const int32_t *plan, const int32_t *desc, int *grid) {
+    if (P.L > (1 << 28)) return 1;                        // 32-bit sample offsets in the bounds-checked loads
     const int n_waves = APW_WAVES, x_complex = APW_X_COMPLEX;
     const int M = P.n_mels;
     W.y = P.y;
@@ -508,6 +509,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
 template <class W512>
 static inline int ap_prepare_stft_wave512(W512 &W, const ApStftParams &P, int64_t B, int n_waves,
                                           int x_complex, int ob_complex, int *grid) {
+    if (P.L > (1 << 28)) return 1;
     if (P.T > (1 << 20)) return 1;                        // 32-bit row offsets in the store phase
     W.y = P.y;
     W.window = P.window;
@@ -600,6 +602,7 @@ static inline bool ap_ct_config(int n_fft, int n_parts, int n_quads, int n_mels,
 
 // n_fft = 2048 STFT wave kernel geometry
 static inline int ap_prepare_stft_wave(ApStftWaveParams &W, const ApStftParams &P, int64_t B, int *grid) {
+    if (P.L > (1 << 28)) return 1;                        // 32-bit sample offsets in the bounds-checked loads
     W.y = P.y;
     W.window = P.window;
     W.tw = P.tw;

@@ -79,6 +79,8 @@ static const unsigned kApKeyMinusInf = 0x007FFFFFu;   // ap_fkey(-inf)
 // compile-time specialised engine for n_fft = 400 / 512 / 1024 (kernels_ct.h)
 template <int EPI, int PADGEN>
 static int ap_launch_ct(ApStftParams &P, int n_fft, int64_t B, void *stream, bool *handled) {
+    *handled = false;
+    if (P.L > (1 << 28)) return AP_OK;                   // 32-bit sample offsets in the bounds-checked loads: generic engine
     int G = 0, lds = 0;
     *handled = false;
     if (!ap_ct_config(n_fft, EPI == 1 ? P.n_parts : 0, EPI == 1 ? P.n_quads : 0, P.n_mels, &G, &lds)) return AP_OK;

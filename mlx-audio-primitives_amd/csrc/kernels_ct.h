@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(NT) ap_stft_ct_kernel(ApStftParams P) {
                 if (PADGEN)
                     raw[i] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
                 else
-                    raw[i] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+                    raw[i] = ap_clip_load2(clip, (int)p);
             }
         }
     };

@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int64_t p = base + 2 * (lane + 64 * j);
-                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+                raw[j] = ap_clip_load2(clip, (int)p);
             }
         } else {
 #pragma unroll
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(64 * APW_WAVES, 2) ap_mel2048_wave_kernel(ApMe
             _Pragma("unroll") for (int j = 0; j < 16 - (S); ++j) raw[j] = raw[j + (S)];      \
             _Pragma("unroll") for (int j = 16 - (S); j < 16; ++j) {                           \
                 const int64_t p = base + 2 * (lane + 64 * j);                                \
-                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));            \
+                raw[j] = ap_clip_load2(clip, (int)p);            \
             }                                                                                \
         }
         if (P.hopj == 4) APW_SHIFT_LOAD(4)
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_wave_kernel(ApS
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int64_t p = base + 2 * (lane + 64 * j);
-                raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+                raw[j] = ap_clip_load2(clip, (int)p);
             }
         } else {
 #pragma unroll

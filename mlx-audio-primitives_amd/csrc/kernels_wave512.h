@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(Ap
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int64_t p = base + 2 * (lane + 64 * j);
-            raw[j] = ap_mk(ap_clip_load(clip, p), ap_clip_load(clip, p + 1));
+            raw[j] = ap_clip_load2(clip, (int)p);
         }
     };
     const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
