@@ -24,6 +24,7 @@ from .windows import get_window
 __version__ = "0.1.0"
 
 __all__ = [
+    "__version__",
     "HAS_HIP_EXT", "_ext",
     "stft", "istft", "magnitude", "phase", "check_nola",
     "get_window",
