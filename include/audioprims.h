@@ -439,6 +439,14 @@ int ap_autocorrelation_f32(const float *y /*dev (B,n)*/, int64_t B, int64_t n, i
                            int center, const float *tw1 /*dev*/, const float *tw2 /*dev*/, float *ws /*dev*/,
                            float *out /*dev*/, void *stream);
 
+/* pitch_detect_acf / periodicity (reference pitch.py:118-369) from the raw autocorrelation r (rows, n_lag) of
+ * every centred frame: on r / r[0] over the lags min_lag .. max_lag the first local maximum above `threshold`
+ * (else the global maximum, if above it) gives f0 = sr / lag and voiced = 1; periodicity = the maximum.
+ * Rows with r[0] <= 1e-10 stay 0.  Any of the three outputs may be NULL. */
+int ap_acf_peaks_f32(const float *r /*dev*/, int64_t rows, int n_lag, int min_lag, int max_lag,
+                     float threshold, float sr, float *f0 /*dev (rows)*/,
+                     unsigned char *voiced /*dev (rows)*/, float *periodicity /*dev (rows)*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

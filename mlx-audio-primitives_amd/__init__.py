@@ -15,7 +15,7 @@ from .framing import deemphasis, frame, preemphasis, rms
 from .griffinlim import griffinlim
 from .mel import filterbank_spectrogram, hz_to_mel, mel_filterbank, mel_to_hz, melspectrogram, pcm16_to_float
 from .mfcc import dct, delta, mfcc
-from .pitch import autocorrelation
+from .pitch import autocorrelation, periodicity, pitch_detect_acf
 from .resample import resample, resample_poly
 from .stft import check_nola, istft, magnitude, phase, stft
 from .streaming import StreamingSTFT
@@ -31,7 +31,7 @@ __all__ = [
     "hz_to_mel", "mel_to_hz", "mel_filterbank", "melspectrogram",
     "griffinlim", "resample", "resample_poly",
     "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "spectral_features",
-    "StreamingSTFT", "autocorrelation", "pcm16_to_float", "hz_to_bark", "bark_to_hz", "bark_filterbank", "linear_filterbank", "filterbank_spectrogram",
+    "StreamingSTFT", "autocorrelation", "pitch_detect_acf", "periodicity", "pcm16_to_float", "hz_to_bark", "bark_to_hz", "bark_filterbank", "linear_filterbank", "filterbank_spectrogram",
     "zero_crossing_rate", "frame", "rms", "preemphasis", "deemphasis", "delta",
     "mfcc", "dct", "power_to_db", "db_to_power", "amplitude_to_db", "db_to_amplitude",
     "validate_positive", "validate_non_negative", "validate_range",

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
     "ap_spectral_stats_f32", "ap_spectral_audio_fused", "ap_spectral_audio_f32", "ap_frame_stats_f32", "ap_preemphasis_f32", "ap_deemphasis_f32", "ap_deemphasis_workspace_floats", "ap_deemphasis_ws_f32", "ap_savgol_f32",
-    "ap_autocorrelation_nfft", "ap_autocorrelation_f32",
+    "ap_autocorrelation_nfft", "ap_autocorrelation_f32", "ap_acf_peaks_f32",
     "ap_pcm16_to_f32", "ap_melspec_pcm16_fused", "ap_melspec_pcm16_f32",
 ]
 
@@ -115,6 +115,7 @@ def _declare(lib) -> None:
         "ap_deemphasis_ws_f32": [P, L, L, F, P, P, P, P, P],
         "ap_savgol_f32": [P, L, L, L, P, I, I, F, P, P, P],
         "ap_autocorrelation_f32": [P, L, L, L, I, I, P, P, P, P, P],
+        "ap_acf_peaks_f32": [P, L, I, I, I, F, F, P, P, P, P],
         "ap_pcm16_to_f32": [P, L, F, P, P],
         "ap_melspec_pcm16_fused": [L, I, I, I, I, I, F, P],
         "ap_melspec_pcm16_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P, P, P],

@@ -1053,6 +1053,16 @@ int ap_autocorrelation_f32(const float *y, int64_t B, int64_t n, int64_t max_lag
     return ap_check_launch("ap_autocorrelation_f32");
 }
 
+int ap_acf_peaks_f32(const float *r, int64_t rows, int n_lag, int min_lag, int max_lag, float threshold, float sr,
+                     float *f0, unsigned char *voiced, float *periodicity, void *stream) {
+    if (!r) AP_FAIL(AP_ERR_INVALID, "pitch: NULL buffer");
+    if (rows <= 0 || n_lag <= 0) AP_FAIL(AP_ERR_INVALID, "pitch: empty autocorrelation");
+    if (min_lag < 0) AP_FAIL(AP_ERR_INVALID, "pitch: negative lag");
+    hipLaunchKernelGGL(ap_acf_peak_kernel, dim3((unsigned)((rows + AP_BLOCK - 1) / AP_BLOCK)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, r, rows, n_lag, min_lag, max_lag, threshold, sr, f0, voiced, periodicity);
+    return ap_check_launch("ap_acf_peaks_f32");
+}
+
 int ap_pcm16_to_f32(const int16_t *x, int64_t n, float scale, float *out, void *stream) {
     if (n < 0 || (n > 0 && (!x || !out))) AP_FAIL(AP_ERR_INVALID, "pcm16_to_f32: bad buffer");
     if (n == 0) return AP_OK;

@@ -659,3 +659,39 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_extend_kernel(const float *x, int
         out[e] = ap_extend_sample(x + b * L, L, i, mode);
     }
 }
+
+// Pitch from the autocorrelation of every frame (reference pitch.py:118-369: pitch_detect_acf, periodicity):
+// r (rows, n_lag) is the RAW autocorrelation of the centred frames (lags 0 .. n_lag - 1; lags past the frame
+// are 0).  Per row, on r / r[0] over the lags min_lag .. max_lag: the first local maximum above `threshold`
+// (else the global maximum if it is above it) gives f0 = sr / lag; the maximum itself is the periodicity.
+// Rows with r[0] <= 1e-10 (silence) stay unvoiced / 0.  One thread per row.
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_acf_peak_kernel(const float *r, int64_t rows, int n_lag, int min_lag, int max_lag, float threshold, float sr,
+                   float *f0, unsigned char *voiced, float *periodicity) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float *rr = r + row * n_lag;
+    const float r0 = rr[0];
+    float f = 0.0f, per = 0.0f;
+    unsigned char v = 0;
+    if (r0 > 1e-10f && max_lag >= min_lag) {
+        auto at = [&](int lag) { return lag < n_lag ? rr[lag] / r0 : 0.0f; };
+        int first = -1, arg = min_lag;
+        float best = at(min_lag);
+        float prev = best, cur = max_lag > min_lag ? at(min_lag + 1) : best;
+        if (cur > best) { best = cur; arg = min_lag + 1; }
+        for (int lag = min_lag + 1; lag < max_lag; ++lag) {            // interior points of the search range
+            const float next = at(lag + 1);
+            if (first < 0 && cur > prev && cur > next && cur > threshold) first = lag;
+            if (next > best) { best = next; arg = lag + 1; }
+            prev = cur;
+            cur = next;
+        }
+        per = best;
+        const int lag = first >= 0 ? first : (best > threshold ? arg : -1);
+        if (lag > 0) { f = sr / (float)lag; v = 1; }
+    }
+    if (f0) f0[row] = f;
+    if (voiced) voiced[row] = v;
+    if (periodicity) periodicity[row] = per;
+}

@@ -334,3 +334,41 @@ def test_rms_zcr_block_kernel_vs_span_kernel_and_oracle(frame_length, hop, L, B,
     np.testing.assert_array_equal(z, z2)
     np.testing.assert_allclose(r, ao.rms(y, **kw), rtol=1e-5, atol=1e-7)
     np.testing.assert_array_equal(z, ao.zero_crossing_rate(y, **kw))
+
+
+# ------------------------------------------------------------------ pitch_detect_acf / periodicity
+def _tones(B, L, sr, freqs, noise=0.02, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(L) / sr
+    y = np.stack([np.sin(2 * np.pi * f * t) + 0.4 * np.sin(2 * np.pi * 2 * f * t) for f in freqs[:B]])
+    return (y + noise * rng.standard_normal((B, L))).astype(np.float32)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(fmin=80.0, fmax=500.0, frame_length=1024, hop_length=256),
+                                dict(center=False, threshold=0.3), dict(sr=16000, fmin=60.0, fmax=400.0)])
+def test_pitch_detect_acf_and_periodicity(kw):
+    """reference pitch.py:118-369 (tests/test_pitch.py: a 220 Hz tone is found within a few Hz; silence is
+    unvoiced): frames + device autocorrelation + peak pass against the oracle's restatement."""
+    sr = kw.get("sr", 22050)
+    y = _tones(4, 20000, sr, [110.0, 220.0, 330.0, 147.0])
+    y[3, 5000:12000] = 0.0                                    # a silent stretch: unvoiced frames, periodicity 0
+    f0, voiced = ap.pitch_detect_acf(dev(y), **kw)
+    wf0, wv = ao.pitch_detect_acf(y, **kw)
+    assert f0.shape == wf0.shape and voiced.dtype == torch.bool
+    agree = host(voiced) == wv
+    assert agree.mean() > 0.995                               # float32 vs float64 r at the threshold
+    both = agree & wv
+    close = np.isclose(host(f0)[both], wf0[both], rtol=1e-6)
+    assert close.mean() > 0.995                               # a tie between neighbouring lags may flip
+    pk = {k: v for k, v in kw.items() if k != "threshold"}
+    p = host(ap.periodicity(dev(y), **pk))
+    np.testing.assert_allclose(p, ao.periodicity(y, **pk), rtol=1e-4, atol=2e-5)
+    assert p.shape == (4, 1, f0.shape[1])
+    # the tone clips are found
+    med = np.median(host(f0)[1][host(voiced)[1]])
+    assert abs(med - 220.0) < 4.0
+    f1, v1 = ap.pitch_detect_acf(dev(y[0]), **kw)
+    assert f1.shape == (f0.shape[1],)
+    np.testing.assert_array_equal(host(f1), host(f0)[0])
+    with pytest.raises(ValueError, match="must be less than fmax"):
+        ap.pitch_detect_acf(dev(y), fmin=500.0, fmax=100.0)

@@ -196,3 +196,42 @@ def test_upfirdn_extend_pinned_to_scipy(mode):
             if n_ext > 0:
                 np.testing.assert_array_equal(ao.upfirdn_extend(x, n_ext, mode),
                                               _pad_test(x, npre=n_ext, npost=n_ext, mode=mode))
+
+
+def test_pitch_oracle_matches_a_sequential_walk_and_finds_tones():
+    """oracle.pitch_detect_acf / periodicity (vectorised) against a frame-by-frame walk of the same rule
+    (reference pitch.py:203-254, 341-361), and the properties the reference's tests assert: a 220 Hz tone is
+    found, silence is unvoiced with periodicity 0."""
+    sr, N, H = 22050, 1024, 256
+    rng = np.random.default_rng(4)
+    t = np.arange(9000) / sr
+    y = (np.sin(2 * np.pi * 220.0 * t) + 0.3 * np.sin(2 * np.pi * 440.0 * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
+    y[4000:6500] = 0.0
+    f0, voiced = ao.pitch_detect_acf(y, sr=sr, fmin=80.0, fmax=600.0, frame_length=N, hop_length=H, threshold=0.2)
+    per = ao.periodicity(y, sr=sr, fmin=80.0, fmax=600.0, frame_length=N, hop_length=H)
+    lo, hi = int(sr / 600.0), int(sr / 80.0)
+    yp = np.pad(y, N // 2)
+    for ti in range(f0.shape[0]):
+        fr = yp[ti * H: ti * H + N]
+        fr = fr - np.mean(fr)
+        nf = 2 ** int(np.ceil(np.log2(2 * N - 1)))
+        Y = np.fft.rfft(fr, n=nf)
+        r = np.fft.irfft(Y * np.conj(Y), n=nf)
+        if not r[0] > 1e-10:
+            assert f0[ti] == 0 and not voiced[ti] and per[0, ti] == 0
+            continue
+        seg = (r / r[0])[lo:hi + 1]
+        assert np.isclose(per[0, ti], seg.max(), rtol=1e-6)
+        pick = None
+        for i in range(1, len(seg) - 1):
+            if seg[i] > seg[i - 1] and seg[i] > seg[i + 1] and seg[i] > 0.2:
+                pick = i
+                break
+        if pick is None and seg.max() > 0.2:
+            pick = int(np.argmax(seg))
+        if pick is None:
+            assert not voiced[ti] and f0[ti] == 0
+        else:
+            assert voiced[ti] and np.isclose(f0[ti], sr / (lo + pick), rtol=1e-6)
+    assert abs(np.median(f0[:10][voiced[:10]]) - 220.0) < 3.0
+    assert not voiced[20:23].any()                             # frames inside the silent stretch
