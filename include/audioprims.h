@@ -359,6 +359,13 @@ int ap_spectral_stats_f32(const float *S /*dev*/, int is_complex, int64_t B, int
                           float p, int norm, float roll_percent, float amin, float *centroid /*dev or NULL*/,
                           float *bandwidth, float *rolloff, float *flatness, void *stream);
 
+/* spectral_contrast (reference features.py:445-595): bands (n_bands, 3) int32 on the device = first bin, one past
+ * the last bin, number of extreme values k of every octave band (host-built from the bin frequencies as the
+ * reference does); out (B, n_bands, T) = mean of the k largest minus mean of the k smallest magnitudes of the band,
+ * as 10 log10 differences unless `linear`. */
+int ap_spectral_contrast_f32(const float *S /*dev (B,F,T)*/, int64_t B, int64_t F, int64_t T,
+                             const int32_t *bands /*dev*/, int n_bands, int linear, float *out /*dev*/, void *stream);
+
 /* The same statistics straight from the audio for n_fft = 2048 (reference features.py:24-55: every
  * feature call runs its own STFT first): transform, |X|^power and the per-frame reductions in ONE kernel,
  * the complex spectrum never reaches HBM.  ap_spectral_audio_fused: 1 when the shape is served (n_fft

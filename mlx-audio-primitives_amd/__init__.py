@@ -8,7 +8,7 @@ kernel behind the C ABI in include/audioprims.h.  There is no CPU fallback.
 from ._extension import HAS_HIP_EXT, _ext
 from ._validation import validate_non_negative, validate_positive, validate_range
 from .convert import amplitude_to_db, db_to_amplitude, db_to_power, power_to_db
-from .features import (spectral_bandwidth, spectral_centroid, spectral_features, spectral_flatness,
+from .features import (spectral_bandwidth, spectral_centroid, spectral_contrast, spectral_features, spectral_flatness,
                        spectral_rolloff, zero_crossing_rate)
 from .filterbanks import bark_filterbank, bark_to_hz, hz_to_bark, linear_filterbank
 from .framing import deemphasis, frame, preemphasis, rms
@@ -30,7 +30,7 @@ __all__ = [
     "get_window",
     "hz_to_mel", "mel_to_hz", "mel_filterbank", "melspectrogram",
     "griffinlim", "resample", "resample_poly",
-    "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "spectral_features",
+    "spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "spectral_contrast", "spectral_features",
     "StreamingSTFT", "autocorrelation", "pitch_detect_acf", "periodicity", "pcm16_to_float", "hz_to_bark", "bark_to_hz", "bark_filterbank", "linear_filterbank", "filterbank_spectrogram",
     "zero_crossing_rate", "frame", "rms", "preemphasis", "deemphasis", "delta",
     "mfcc", "dct", "power_to_db", "db_to_power", "amplitude_to_db", "db_to_amplitude",

@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
     "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
-    "ap_spectral_stats_f32", "ap_spectral_audio_fused", "ap_spectral_audio_f32", "ap_frame_stats_f32", "ap_preemphasis_f32", "ap_deemphasis_f32", "ap_deemphasis_workspace_floats", "ap_deemphasis_ws_f32", "ap_savgol_f32",
+    "ap_spectral_stats_f32", "ap_spectral_audio_fused", "ap_spectral_audio_f32", "ap_spectral_contrast_f32", "ap_frame_stats_f32", "ap_preemphasis_f32", "ap_deemphasis_f32", "ap_deemphasis_workspace_floats", "ap_deemphasis_ws_f32", "ap_savgol_f32",
     "ap_autocorrelation_nfft", "ap_autocorrelation_f32", "ap_acf_peaks_f32",
     "ap_pcm16_to_f32", "ap_melspec_pcm16_fused", "ap_melspec_pcm16_f32",
 ]
@@ -108,6 +108,7 @@ def _declare(lib) -> None:
         "ap_phase_f32": [P, L, P, P],
         "ap_spectral_stats_f32": [P, I, L, L, L, P, F, P, F, I, F, F, P, P, P, P, P],
         "ap_spectral_audio_fused": [L, I, I, I, I],
+        "ap_spectral_contrast_f32": [P, L, L, L, P, I, I, P, P],
         "ap_spectral_audio_f32": [P, L, L, I, I, P, P, I, I, L, P, F, F, I, F, F, P, P, P, P, P],
         "ap_frame_stats_f32": [P, L, L, I, I, I, I, L, P, P, P],
         "ap_preemphasis_f32": [P, L, L, F, P, P, P, P],

@@ -1053,6 +1053,19 @@ int ap_autocorrelation_f32(const float *y, int64_t B, int64_t n, int64_t max_lag
     return ap_check_launch("ap_autocorrelation_f32");
 }
 
+int ap_spectral_contrast_f32(const float *S, int64_t B, int64_t F, int64_t T, const int32_t *bands_dev, int n_bands,
+                             int linear, float *out, void *stream) {
+    if (!S || !bands_dev || !out) AP_FAIL(AP_ERR_INVALID, "spectral_contrast: NULL buffer");
+    if (B <= 0 || F <= 0 || T <= 0)
+        AP_FAIL(AP_ERR_INVALID, "S must be 2D (freq_bins, n_frames) or 3D (batch, freq_bins, n_frames)");
+    if (n_bands <= 0 || n_bands > 65535) AP_FAIL(AP_ERR_INVALID, "n_bands must be positive");
+    const int64_t blocks = (B * T + AP_BLOCK - 1) / AP_BLOCK;
+    if (blocks > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "spectral_contrast: grid too large");
+    hipLaunchKernelGGL(ap_spectral_contrast_kernel, dim3((unsigned)blocks, (unsigned)n_bands), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, S, B, F, T, bands_dev, linear, out);
+    return ap_check_launch("ap_spectral_contrast_f32");
+}
+
 int ap_acf_peaks_f32(const float *r, int64_t rows, int n_lag, int min_lag, int max_lag, float threshold, float sr,
                      float *f0, unsigned char *voiced, float *periodicity, void *stream) {
     if (!r) AP_FAIL(AP_ERR_INVALID, "pitch: NULL buffer");

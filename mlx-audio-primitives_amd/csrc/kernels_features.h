@@ -695,3 +695,65 @@ ap_acf_peak_kernel(const float *r, int64_t rows, int n_lag, int min_lag, int max
     if (voiced) voiced[row] = v;
     if (periodicity) periodicity[row] = per;
 }
+
+// Spectral contrast (reference features.py:445-595, librosa's rule): for every frame and octave band the mean of
+// the k smallest and the mean of the k largest magnitudes of the band's bins [lo, hi); contrast = their
+// difference, in dB unless `linear`.  The reference sorts every band on the host; k is a small fraction of the
+// band (quantile 0.02: 1-9 values), so a thread extracts the k extremes by repeated selection instead - each
+// pass finds the next element in (value, bin) order, so ties are taken once each - from rows that are coalesced
+// across the frames of a workgroup and stay in L1 / L2 between passes.  One thread per (clip, frame), one
+// grid row per band.
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_spectral_contrast_kernel(const float *S, int64_t B, int64_t F, int64_t T, const int32_t *bands /* [n][3]: lo, hi, k */,
+                            int linear, float *out /* (B, n, T) */) {
+    const int band = blockIdx.y, n_bands = gridDim.y;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * T) return;
+    const int64_t b = e / T, t = e - b * T;
+    const int lo = bands[3 * band], hi = bands[3 * band + 1];
+    int k = bands[3 * band + 2];
+    float valley = 0.0f, peak = 0.0f;
+    if (hi > lo) {
+        if (k > hi - lo) k = hi - lo;
+        const float *col = S + b * F * T + t;
+        // k smallest, ascending: next element after (pv, pi) in (value, bin) order
+        float pv = -INFINITY, sum = 0.0f;
+        int pi = -1;
+        for (int j = 0; j < k; ++j) {
+            float bv = INFINITY;
+            int bi = -1;
+            for (int i = lo; i < hi; ++i) {
+                const float v = col[(int64_t)i * T];
+                const bool after = v > pv || (v == pv && i > pi);
+                if (after && (v < bv || bi < 0)) { bv = v; bi = i; }
+            }
+            if (bi < 0) break;                     // NaNs: nothing comparable is left
+            sum += bv;
+            pv = bv;
+            pi = bi;
+        }
+        valley = sum / (float)k;
+        // k largest, descending
+        pv = INFINITY;
+        pi = hi;
+        sum = 0.0f;
+        for (int j = 0; j < k; ++j) {
+            float bv = -INFINITY;
+            int bi = -1;
+            for (int i = hi - 1; i >= lo; --i) {
+                const float v = col[(int64_t)i * T];
+                const bool before = v < pv || (v == pv && i < pi);
+                if (before && (v > bv || bi < 0)) { bv = v; bi = i; }
+            }
+            if (bi < 0) break;
+            sum += bv;
+            pv = bv;
+            pi = bi;
+        }
+        peak = sum / (float)k;
+    }
+    float c;
+    if (linear) c = peak - valley;
+    else c = 10.0f * log10f(fmaxf(peak, 1e-10f)) - 10.0f * log10f(fmaxf(valley, 1e-10f));
+    out[(b * n_bands + band) * T + t] = c;
+}

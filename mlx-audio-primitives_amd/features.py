@@ -8,7 +8,7 @@ STFT kernel and ONE statistics kernel that takes |X| (and |X|**power) on load fr
 spectrum — the reference's magnitude / power / sum / cumsum / argmax tensors
 (features.py:24-55,115-134,342-360) are never materialised.  From a given
 spectrogram S the same kernel reads S once.  ``spectral_contrast`` (a host NumPy sort per octave band
-in the reference, features.py:445-595) is outside the hot path and not built.
+in the reference, features.py:445-595) is one selection kernel over the octave bands.
 """
 
 from __future__ import annotations
@@ -186,3 +186,68 @@ def zero_crossing_rate(y, frame_length: int = 2048, hop_length: int = 512, cente
     from .framing import _frame_stats
 
     return _frame_stats(y, frame_length, hop_length, center, pad_mode, "zcr")
+
+
+def _contrast_bands(freq: np.ndarray, fmin: float, n_bands: int, quantile: float) -> np.ndarray:
+    """(n_bands + 1, 3) int32: first bin, one past the last bin and the number of extreme values of every
+    octave band [0, fmin], [fmin, 2 fmin], ... (librosa's rule as the reference applies it, features.py:528-561:
+    the neighbour bin below joins every band but the first, the last band runs to Nyquist, the count comes from
+    the band BEFORE its top bin is dropped, every band but the last drops its top bin)."""
+    edges = np.zeros(n_bands + 2)
+    edges[1:] = fmin * (2.0 ** np.arange(0, n_bands + 1))
+    F = freq.shape[0]
+    rows = np.zeros((n_bands + 1, 3), np.int32)
+    for k in range(n_bands + 1):
+        inside = np.flatnonzero((freq >= edges[k]) & (freq <= edges[k + 1]))
+        if inside.size == 0:
+            continue
+        lo, hi = int(inside[0]), int(inside[-1]) + 1
+        if k > 0 and lo > 0:
+            lo -= 1
+        if k == n_bands:
+            hi = F
+        count = hi - lo
+        n_q = int(max(np.rint(quantile * count), 1))
+        if k < n_bands and count > 1:
+            hi -= 1
+        rows[k] = (lo, hi, n_q)
+    return rows
+
+
+def spectral_contrast(y=None, sr: int = 22050, S=None, n_fft: int = 2048, hop_length: int = 512,
+                      win_length: int | None = None, window="hann", center: bool = True,
+                      pad_mode: str = "constant", freq=None, fmin: float = 200.0, n_bands: int = 6,
+                      quantile: float = 0.02, linear: bool = False) -> torch.Tensor:
+    """Peak-to-valley contrast of every octave band and frame (reference features.py:445-595):
+    (n_bands + 1, n_frames) or (batch, n_bands + 1, n_frames)."""
+    validate_positive(n_bands, "n_bands")
+    validate_range(quantile, "quantile", min_val=0.0, max_val=1.0)
+    if S is not None:
+        S = _x.to_device_f32(S)
+    else:
+        if y is None:
+            raise ValueError("Either y (audio) or S (spectrogram) must be provided")
+        from .stft import magnitude
+        S = magnitude(stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window,
+                           center=center, pad_mode=pad_mode))
+    if S.ndim not in (2, 3):
+        raise ValueError("S must be 2D (freq_bins, n_frames) or 3D (batch, freq_bins, n_frames)")
+    batched = S.ndim == 3
+    if not batched:
+        S = S[None]
+    S = S.contiguous()
+    B, F, T = S.shape
+    dev = S.device
+    if freq is None:
+        fr = np.linspace(0, sr / 2.0, n_fft // 2 + 1).astype(np.float32)
+    else:
+        fr = np.asarray(freq.detach().cpu() if isinstance(freq, torch.Tensor) else freq, dtype=np.float32).reshape(-1)
+    if fr.shape[0] != F:
+        raise ValueError(f"freq must be 1D with {F} entries (freq_bins), got shape {tuple(fr.shape)}")
+    bands = _contrast_bands(fr, float(fmin), int(n_bands), float(quantile))
+    out = torch.empty((B, n_bands + 1, T), dtype=torch.float32, device=dev)
+    if B > 0 and T > 0:
+        bd = torch.from_numpy(bands).to(dev)
+        _x.check(_x.dlib(dev).ap_spectral_contrast_f32(_x.ptr(S), B, F, T, _x.ptr(bd), n_bands + 1, int(bool(linear)),
+                                                       _x.ptr(out), _x.stream_ptr(dev)))
+    return out if batched else out[0]

@@ -45,6 +45,59 @@ def test_spectral_centroid_bandwidth_flatness(random_signal, n_fft, hop):
         np.testing.assert_allclose(f, ao.spectral_flatness(random_signal, power=power, **kw), rtol=2e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("n_bands,quantile,linear", [(6, 0.02, False), (4, 0.02, True), (8, 0.1, False),
+                                                      (6, 0.5, True), (6, 1.0, False), (6, 0.0, True)])
+def test_spectral_contrast(random_signal, chirp_signal, n_bands, quantile, linear):
+    """reference features.py:445-595 / tests/test_features.py:259-291 (its librosa comparison is absent here:
+    the oracle restates the band rule and is checked against a per-frame walk in test_oracle_golden)."""
+    kw = dict(sr=22050, n_bands=n_bands, quantile=quantile, linear=linear)
+    for sig in (random_signal, chirp_signal):
+        got = ap.spectral_contrast(dev(sig), **kw)
+        assert got.shape == (n_bands + 1, 1 + len(sig) // 512) and got.dtype == torch.float32
+        S = host(ap.magnitude(ap.stft(dev(sig))))
+        want = ao.spectral_contrast(S=S, **kw)
+        if linear:
+            np.testing.assert_allclose(host(got), want, rtol=2e-5, atol=1e-5 * float(np.abs(S).max()))
+        else:
+            np.testing.assert_allclose(host(got), want, rtol=1e-5, atol=2e-4)
+        np.testing.assert_array_equal(host(ap.spectral_contrast(S=dev(S), **kw)), host(got))
+    # the whole path from audio stays within the STFT's own tolerance of the oracle's
+    np.testing.assert_allclose(host(ap.spectral_contrast(dev(random_signal), **kw)),
+                               ao.spectral_contrast(random_signal, **kw), rtol=1e-3, atol=2e-2 if not linear else 2e-3)
+
+
+def test_spectral_contrast_batched_other_grids_and_edges(batch_signals):
+    y = dev(batch_signals)
+    for kw in (dict(sr=16000, n_fft=512, hop_length=128, n_bands=5, fmin=100.0),
+               dict(sr=16000, n_fft=400, hop_length=160, n_bands=6, fmin=200.0),       # top edge past Nyquist
+               dict(sr=8000, n_fft=256, hop_length=64, n_bands=7, fmin=200.0),         # empty top bands
+               dict(sr=22050, n_fft=1024, hop_length=256, n_bands=3, fmin=20.0, quantile=0.3)):
+        S = host(ap.magnitude(ap.stft(y, n_fft=kw["n_fft"], hop_length=kw["hop_length"])))
+        got = host(ap.spectral_contrast(y, **kw))
+        assert got.shape == (batch_signals.shape[0], kw["n_bands"] + 1, S.shape[-1])
+        np.testing.assert_allclose(got, ao.spectral_contrast(S=S, **kw), rtol=1e-5, atol=2e-4)
+    # ties and constant columns: every selection order gives the same sums
+    S = np.ones((2, 1025, 7), np.float32)
+    S[:, ::3] = 0.25
+    for linear in (True, False):
+        np.testing.assert_allclose(host(ap.spectral_contrast(S=dev(S), linear=linear, quantile=0.2)),
+                                   ao.spectral_contrast(S=S, linear=linear, quantile=0.2), rtol=1e-6, atol=1e-5)
+    z = host(ap.spectral_contrast(S=torch.zeros(1025, 3).cuda()))
+    assert z.shape == (7, 3) and (z == 0).all()                                        # both clamp to amin
+    # custom bin centres, and the validation messages of the reference
+    f = np.linspace(0, 4000.0, 1025).astype(np.float32)
+    Sr = np.abs(np.random.default_rng(5).standard_normal((1025, 9))).astype(np.float32)
+    np.testing.assert_allclose(host(ap.spectral_contrast(S=dev(Sr), freq=dev(f))), ao.spectral_contrast(S=Sr, freq=f),
+                               rtol=1e-5, atol=2e-4)
+    with pytest.raises(ValueError, match="n_bands must be positive"):
+        ap.spectral_contrast(S=dev(Sr), n_bands=0)
+    with pytest.raises(ValueError, match="quantile must be"):
+        ap.spectral_contrast(S=dev(Sr), quantile=1.5)
+    with pytest.raises(ValueError, match="Either y"):
+        ap.spectral_contrast()
+    assert ap.spectral_contrast(S=torch.zeros(2, 1025, 0).cuda()).shape == (2, 7, 0)
+
+
 def _rolloff_agrees(got, want, freq, frac=0.02):
     """The rolloff is a bin frequency: where the float32 running sum meets the threshold within
     rounding, another summation order may pick the neighbouring bin.  Allow that for < 2 % of frames."""

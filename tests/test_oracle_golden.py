@@ -235,3 +235,39 @@ def test_pitch_oracle_matches_a_sequential_walk_and_finds_tones():
             assert voiced[ti] and np.isclose(f0[ti], sr / (lo + pick), rtol=1e-6)
     assert abs(np.median(f0[:10][voiced[:10]]) - 220.0) < 3.0
     assert not voiced[20:23].any()                             # frames inside the silent stretch
+
+
+def test_spectral_contrast_oracle_matches_a_per_frame_walk():
+    """features.py:445-595 restated twice: the oracle's vectorised sort against a bin-by-bin walk written from the
+    rule's text (librosa, which the reference's tests/test_features.py:262-275 compares with, is absent here:
+    "parity unpinned" beyond this and the properties below)."""
+    rng = np.random.default_rng(11)
+    sr, n_fft, n_bands, fmin, q = 22050, 2048, 6, 200.0, 0.02
+    S = np.abs(rng.standard_normal((n_fft // 2 + 1, 6))).astype(np.float32)
+    f = ao.fft_frequencies(sr, n_fft)
+    got = ao.spectral_contrast(S=S, sr=sr, n_fft=n_fft, n_bands=n_bands, fmin=fmin, quantile=q, linear=True)
+    assert got.shape == (n_bands + 1, 6)
+    lows = [0.0] + [fmin * 2 ** i for i in range(n_bands)]
+    for k in range(n_bands + 1):
+        bins = [i for i in range(len(f)) if lows[k] <= f[i] <= (fmin * 2 ** k)]
+        if k > 0:
+            bins = [bins[0] - 1] + bins
+        if k == n_bands:
+            bins = list(range(bins[0], len(f)))
+        take = max(int(round(q * len(bins))), 1)
+        if k < n_bands:
+            bins = bins[:-1]
+        for t in range(6):
+            col = sorted(float(S[i, t]) for i in bins)
+            want = sum(col[-take:]) / take - sum(col[:take]) / take
+            assert abs(got[k, t] - want) < 1e-5, (k, t)
+    # a tone stands far above the valley of its own band only; noise has a few dB everywhere
+    tt = np.arange(sr, dtype=np.float64) / sr
+    tone = (np.sin(2 * np.pi * 1000.0 * tt) + 1e-3 * rng.standard_normal(sr)).astype(np.float32)
+    c = ao.spectral_contrast(tone, sr=sr)
+    assert c.shape == (7, 1 + sr // 512)
+    assert c[3, 2:-2].min() > 40.0 and c[5, 2:-2].max() < 30.0          # 800-1600 Hz holds the tone
+    n = ao.spectral_contrast(rng.standard_normal(sr).astype(np.float32), sr=sr)
+    assert 5.0 < n.mean() < 30.0 and (n >= 0).all()
+    with pytest.raises(ValueError, match="quantile must be"):
+        ao.spectral_contrast(tone, quantile=-0.1)
