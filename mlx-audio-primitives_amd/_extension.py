@@ -435,6 +435,83 @@ class _Ext:
         t = torch.from_numpy(dct_matrix_host(n_out, n_in, norm))
         return t.to(require_device()) if torch.cuda.is_available() else t
 
+    def autocorrelation(self, signal, max_lag=-1, normalize=True, center=True, stream=None):
+        """bindings.cpp:224-231 (max_lag < 0: all lags), the call pitch.py:59-64 makes."""
+        from .pitch import autocorrelation as _acf
+
+        return _acf(signal, max_lag=None if max_lag is None or max_lag < 0 else max_lag, normalize=normalize,
+                    center=center)
+
+    # spectral.cpp:8-257 — one statistics kernel (ap_spectral_stats_f32) behind all four.  The native reference
+    # guards its quotients with max(sum, 1e-10) (spectral.cpp:47,114) and divides the flatness by the bare mean
+    # (:250) where its Python twins add 1e-10 (features.py:128,262,437): the same to float32 rounding unless a
+    # whole column is below 1e-9, where this mirror follows the Python twins.
+    def spectral_centroid(self, S, frequencies, stream=None):
+        from .features import spectral_centroid as _f
+
+        return _f(S=S, freq=frequencies)
+
+    def spectral_bandwidth(self, S, frequencies, centroid, p=2.0, stream=None):
+        """bindings.cpp:398-405: an empty `centroid` means "compute it" (spectral.cpp:88-96)."""
+        from .features import spectral_bandwidth as _f
+
+        if centroid is not None and int(np.prod(tuple(centroid.shape))) == 0:
+            centroid = None
+        return _f(S=S, freq=frequencies, centroid=centroid, p=p)
+
+    def spectral_rolloff(self, S, frequencies, roll_percent=0.85, stream=None):
+        """bindings.cpp:430-436, the call features.py:352 makes."""
+        from .features import spectral_rolloff as _f
+
+        return _f(S=S, freq=frequencies, roll_percent=roll_percent)
+
+    def spectral_flatness(self, S, amin=1e-10, stream=None):
+        from .features import spectral_flatness as _f
+
+        return _f(S=S, amin=amin)
+
+    def resample_fft(self, signal, num_samples, stream=None):
+        """resample.cpp:9-98: full complex spectrum cut or zero-filled in the middle, real part of the inverse,
+        times num_samples / n.  That is scipy.signal.resample (our `resample(res_type="fft")` engine) except
+        when shrinking to an even length M: SciPy folds the bins +M/2 and -M/2 together, the native code keeps
+        only -M/2 — half the Nyquist term, Re X[M/2] (-1)^j / n, taken off here.  Unreachable from the reference's
+        public API (resample.py never calls `_ext`) and only shape-tested there (test_cpp_extension.py:91-124)."""
+        import torch
+
+        from .resample import _resample_fft_length
+
+        x = to_device_f32(signal)
+        if x.ndim not in (1, 2):
+            raise ValueError("signal must be 1-dimensional (samples,) or 2-dimensional (batch, samples)")
+        if num_samples <= 0:
+            raise ValueError("num_samples must be positive")
+        n = x.shape[-1]
+        if num_samples == n:
+            return x
+        out = _resample_fft_length(x, int(num_samples))
+        if num_samples < n and num_samples % 2 == 0:
+            j = np.arange(n, dtype=np.float64)
+            c = torch.from_numpy(np.cos(2.0 * np.pi * ((num_samples // 2) * j % n) / n).astype(np.float32)).to(x.device)
+            nyq = (x * c).sum(-1, keepdim=True) / n
+            sign = torch.ones(num_samples, dtype=torch.float32, device=x.device)
+            sign[1::2] = -1.0
+            out = out - nyq * sign
+        return out
+
+    def resample(self, signal, orig_sr, target_sr, fix=True, scale=False, stream=None):
+        """resample.cpp:100-149: length round(n ratio) (fix) or ceil(n ratio), then resample_fft, times ratio if
+        `scale`."""
+        if orig_sr <= 0 or target_sr <= 0:
+            raise ValueError("Sample rates must be positive")
+        x = to_device_f32(signal)
+        if orig_sr == target_sr:
+            return x
+        ratio = float(target_sr) / float(orig_sr)
+        n = x.shape[-1]
+        m = int(np.floor(n * ratio + 0.5)) if fix else int(np.ceil(n * ratio))      # std::round: half away from zero
+        out = self.resample_fft(x, m)
+        return out * np.float32(ratio) if scale else out
+
 
 _ext: _Ext | None = _Ext() if HAS_HIP_EXT else None
 

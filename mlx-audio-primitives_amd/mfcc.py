@@ -55,12 +55,11 @@ def dct(x, type: int = 2, n: int | None = None, axis: int = -1, norm: str | None
     return out
 
 
-def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, n_fft: int = 2048,
-         hop_length: int | None = None, win_length: int | None = None, window="hann",
-         center: bool = True, pad_mode: str = "constant", power: float = 2.0, n_mels: int = 128,
-         fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
-         mel_norm: str | None = "slaney", dct_type: int = 2, norm: str | None = "ortho",
-         lifter: int = 0, group=None, _max_reduce=None) -> torch.Tensor:
+def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, dct_type: int = 2, norm: str | None = "ortho",
+         lifter: int = 0, n_fft: int = 2048, hop_length: int = 512, win_length: int | None = None,
+         window="hann", center: bool = True, pad_mode: str = "constant", power: float = 2.0,
+         n_mels: int = 128, fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
+         mel_norm: str | None = "slaney", group=None, _max_reduce=None) -> torch.Tensor:
     """Mel-frequency cepstral coefficients (reference mfcc.py:143-287).
 
     Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames).

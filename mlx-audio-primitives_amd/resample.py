@@ -184,6 +184,16 @@ def _resample_fft(rows: torch.Tensor, out: torch.Tensor, post_scale: float) -> N
         out.mul_(post_scale)        # `scale=True`: y_new *= ratio (resample.py:126-127)
 
 
+def _resample_fft_length(x: torch.Tensor, n_out: int) -> torch.Tensor:
+    """scipy.signal.resample(x, n_out) along the last axis of a 1-D / 2-D float32 device tensor
+    (the engine behind `_ext.resample_fft`, bindings.cpp:255-260)."""
+    rows = x.reshape(-1, x.shape[-1]).contiguous()
+    out = torch.empty((rows.shape[0], n_out), dtype=torch.float32, device=rows.device)
+    if rows.shape[0] > 0:
+        _resample_fft(rows, out, 1.0)
+    return out.reshape(*x.shape[:-1], n_out)
+
+
 def resample(y, orig_sr: int, target_sr: int, res_type: str = "fft", fix: bool = True,
              scale: bool = False, axis: int = -1) -> torch.Tensor:
     """Resample from orig_sr to target_sr (reference resample.py:21-212)."""

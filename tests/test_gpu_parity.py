@@ -374,6 +374,77 @@ def test_ext_pad_frame_overlap_add():
     np.testing.assert_array_equal(host(w_dev), ao.get_window("hann", 512))
 
 
+def _native_resample_fft(x, m):
+    """resample.cpp:9-98 in NumPy float64: middle of the full spectrum cut out or zero-filled, real part."""
+    n = x.shape[-1]
+    X = np.fft.fft(x.astype(np.float64), axis=-1)
+    if m > n:
+        h = (n + 1) // 2
+        Z = np.concatenate([X[..., :h], np.zeros(x.shape[:-1] + (m - n,), complex), X[..., h:]], axis=-1)
+    else:
+        h = (m + 1) // 2
+        Z = np.concatenate([X[..., :h], X[..., n - (m - h):]], axis=-1)
+    return (np.fft.ifft(Z, axis=-1).real * (m / n)).astype(np.float32)
+
+
+def test_ext_surface_complete_and_matches_native_semantics():
+    """The 17 entry points of bindings.cpp:15-484, as tests/test_cpp_extension.py drives them."""
+    names = ["overlap_add", "frame_signal", "pad_signal", "generate_window", "hz_to_mel", "mel_to_hz", "mel_filterbank",
+             "autocorrelation", "resample_fft", "resample", "get_dct_matrix", "dct", "spectral_centroid",
+             "spectral_bandwidth", "spectral_rolloff", "spectral_flatness"]
+    assert all(callable(getattr(ap._ext, n)) for n in names)
+    rng = np.random.default_rng(8)
+    # autocorrelation (test_cpp_extension.py:32-90)
+    t = np.linspace(0, 1, 1000, dtype=np.float32)
+    sig = np.sin(2 * np.pi * 10 * t).astype(np.float32)
+    r = host(ap._ext.autocorrelation(signal=dev(sig), max_lag=100, normalize=True, center=True))
+    assert r.shape == (100,) and abs(r[0] - 1.0) < 1e-5
+    np.testing.assert_allclose(r, ao.autocorrelation(sig, max_lag=100), rtol=1e-4, atol=1e-5)
+    x4 = rng.standard_normal((4, 500)).astype(np.float32)
+    assert ap._ext.autocorrelation(signal=dev(x4), max_lag=50).shape == (4, 50)
+    np.testing.assert_allclose(host(ap._ext.autocorrelation(dev(x4), -1, False, False)),
+                               ao.autocorrelation(x4, normalize=False, center=False), rtol=1e-4, atol=1e-3)
+    # resample_fft / resample (test_cpp_extension.py:91-124 checks shapes only; the semantics are resample.cpp's)
+    for n, m in ((1000, 2000), (1000, 500), (1000, 501), (999, 400), (999, 1500), (1000, 1001), (22050, 16000)):
+        x = rng.standard_normal((3, n)).astype(np.float32)
+        got = host(ap._ext.resample_fft(signal=dev(x), num_samples=m))
+        assert got.shape == (3, m)
+        np.testing.assert_allclose(got, _native_resample_fft(x, m), rtol=1e-4, atol=2e-5)
+    x = rng.standard_normal(1000).astype(np.float32)
+    np.testing.assert_array_equal(host(ap._ext.resample_fft(dev(x), 1000)), x)
+    assert ap._ext.resample_fft(dev(x), 500).shape == (500,)
+    y = rng.standard_normal(22050).astype(np.float32)
+    got = host(ap._ext.resample(signal=dev(y), orig_sr=22050, target_sr=16000, fix=True, scale=False))
+    assert got.shape == (16000,)
+    np.testing.assert_allclose(got, _native_resample_fft(y, 16000), rtol=1e-4, atol=2e-5)
+    got = host(ap._ext.resample(dev(y[:1001]), 22050, 16000, False, True))
+    m = int(np.ceil(1001 * 16000 / 22050))
+    np.testing.assert_allclose(got, _native_resample_fft(y[:1001], m) * np.float32(16000 / 22050), rtol=1e-4, atol=2e-5)
+    with pytest.raises(ValueError, match="num_samples must be positive"):
+        ap._ext.resample_fft(dev(x), 0)
+    with pytest.raises(ValueError, match="Sample rates must be positive"):
+        ap._ext.resample(dev(x), 0, 16000)
+    # spectral statistics (test_cpp_extension.py:196-336)
+    S = (np.abs(rng.standard_normal((4, 513, 44))) + 0.1).astype(np.float32)
+    f = np.linspace(0, 11025, 513).astype(np.float32)
+    c = ap._ext.spectral_centroid(S=dev(S), frequencies=dev(f))
+    assert c.shape == (4, 1, 44)
+    np.testing.assert_allclose(host(c), ao.spectral_centroid(S=S, freq=f), rtol=1e-4)
+    for cent in (c, torch.empty(0, device="cuda")):
+        bw = ap._ext.spectral_bandwidth(S=dev(S), frequencies=dev(f), centroid=cent, p=2.0)
+        assert bw.shape == (4, 1, 44)
+        np.testing.assert_allclose(host(bw), ao.spectral_bandwidth(S=S, freq=f), rtol=2e-4)
+    r85 = host(ap._ext.spectral_rolloff(S=dev(S[0]), frequencies=dev(f), roll_percent=0.85))
+    r95 = host(ap._ext.spectral_rolloff(S=dev(S[0]), frequencies=dev(f), roll_percent=0.95))
+    assert r85.shape == (1, 44) and (r85 >= 0).all() and (r95 <= 11025).all() and (r95 >= r85 - 1e-5).all()
+    fl = host(ap._ext.spectral_flatness(S=dev(S), amin=1e-10))
+    assert fl.shape == (4, 1, 44) and (fl >= 0).all() and (fl <= 1 + 1e-5).all()
+    tone = np.full((513, 10), 1e-10, np.float32)
+    tone[100] = 1.0
+    assert host(ap._ext.spectral_flatness(S=dev(tone))).mean() < 0.1
+    assert host(ap._ext.spectral_flatness(S=torch.ones(513, 10).cuda())).mean() > 0.99
+
+
 # ------------------------------------------------------------------ properties at BASELINE sizes
 def test_properties_headline_config():
     """B=32 x 10 s @ 22.05 kHz, n_fft=2048 hop=512 n_mels=128 — too big for the oracle to
