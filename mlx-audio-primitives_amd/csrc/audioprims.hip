@@ -673,6 +673,20 @@ int ap_from_db_f32(const float *x, int64_t n, float ref, float div, float *out, 
 
 }  // extern "C"
 
+template <int KT, int DB, int WIDE>
+static int ap_launch_dct_as(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
+                            int64_t inner, int n_out, const ApDbParams &D, float *out, void *stream, int lds) {
+    const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
+    // 16 outputs: five workgroups per CU (<= 96 VGPRs); the pass waits on its row loads, so the fifth wave
+    // per SIMD is worth more than the handful of spilled words (mfcc tail of config 4: 59.9 -> 55.4 us)
+    constexpr int MINB = KT == 16 ? 5 : 1;
+    int rc = ap_allow_lds(ap_dct_kernel<KT, DB, WIDE, MINB>, lds);
+    if (rc != AP_OK) return rc;
+    hipLaunchKernelGGL((ap_dct_kernel<KT, DB, WIDE, MINB>), dim3(grid), dim3(AP_BLOCK), lds, (hipStream_t)stream, x, C,
+                       row_scale, outer, n_in, inner, n_out, D, out);
+    return ap_check_launch("ap_dct_f32");
+}
+
 template <int DB>
 static int ap_launch_dct(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
                          int64_t inner, int n_out, const ApDbParams &D, float *out, void *stream,
@@ -682,20 +696,13 @@ static int ap_launch_dct(const float *x, const float *C, const float *row_scale,
     const int lds = n_in * KT * (int)sizeof(float);
     if (lds > 64 * 1024) return AP_OK;
     *handled = true;
-    const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
-    int rc;
-    if (KT == 16) {
-        rc = ap_allow_lds(ap_dct_kernel<16, DB>, lds);
-        if (rc != AP_OK) return rc;
-        hipLaunchKernelGGL((ap_dct_kernel<16, DB>), dim3(grid), dim3(AP_BLOCK), lds, (hipStream_t)stream, x, C,
-                           row_scale, outer, n_in, inner, n_out, D, out);
-    } else {
-        rc = ap_allow_lds(ap_dct_kernel<32, DB>, lds);
-        if (rc != AP_OK) return rc;
-        hipLaunchKernelGGL((ap_dct_kernel<32, DB>), dim3(grid), dim3(AP_BLOCK), lds, (hipStream_t)stream, x, C,
-                           row_scale, outer, n_in, inner, n_out, D, out);
-    }
-    return ap_check_launch("ap_dct_f32");
+    const int64_t most = outer * inner * (n_in > n_out ? n_in : n_out);
+    const bool wide = most >= ((int64_t)1 << 31);
+    if (KT == 16)
+        return wide ? ap_launch_dct_as<16, DB, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out, stream, lds)
+                    : ap_launch_dct_as<16, DB, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out, stream, lds);
+    return wide ? ap_launch_dct_as<32, DB, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out, stream, lds)
+                : ap_launch_dct_as<32, DB, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out, stream, lds);
 }
 
 extern "C" {

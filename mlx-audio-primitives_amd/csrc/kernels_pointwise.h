@@ -138,15 +138,21 @@ ap_from_db_kernel(const float *x, int64_t n, float ref, float div, float *out) {
 // (mfcc.py:253-262) reads the mel power once and never writes the dB array.
 // One thread per (o, i), all KT outputs of a chunk in registers; the basis sits transposed in
 // LDS ([m][KT], 16-byte broadcast reads) and the loads of 8 input rows are issued together.
-template <int KT, int DB>
-__global__ void __launch_bounds__(AP_BLOCK)
-ap_dct_kernel(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
-              int64_t inner, int n_out, ApDbParams D, float *out) {
+// WIDE = 0: x and out hold < 2^31 elements, so a thread's offset is one 32-bit register beside a
+// row pointer the whole wave shares (global loads with a scalar base); WIDE = 1: 64-bit offsets.
+// A reference level of exactly 1 (power_to_db's default, the only one mfcc uses) skips the division
+// S / ref: dividing by 1 changes no bit.
+template <int KT, int DB, int WIDE, int MINB = 1>
+__global__ void __launch_bounds__(AP_BLOCK, MINB)
+ap_dct_kernel(const float *__restrict__ x, const float *__restrict__ C, const float *__restrict__ row_scale,
+              int64_t outer, int n_in, int64_t inner, int n_out, ApDbParams D, float *__restrict__ out) {
+    typedef typename std::conditional<WIDE != 0, int64_t, uint32_t>::type off_t;
     float *Ct = reinterpret_cast<float *>(ap_smem);                 // [n_in][KT]
     const int64_t total = outer * inner;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float ref = 1.0f, floor_v = 0.0f;
     if (DB) { ref = ap_db_ref(D); floor_v = ap_db_floor(D, ref); }
+    const bool unit_ref = !DB || ref == 1.0f;
     for (int k0 = 0; k0 < n_out; k0 += KT) {
         AP_LDS_BARRIER();
         for (int i = threadIdx.x; i < n_in * KT; i += AP_BLOCK) {
@@ -154,32 +160,61 @@ ap_dct_kernel(const float *x, const float *C, const float *row_scale, int64_t ou
             Ct[i] = k0 + k < n_out ? C[(int64_t)(k0 + k) * n_in + m] : 0.0f;
         }
         AP_LDS_BARRIER();
-        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-            const int64_t o = e / inner, i = e - o * inner;
-            const float *xp = x + o * n_in * inner + i;
-            float *op = out + o * n_out * inner + i;
-            float acc[KT];
+        auto sweep = [&](auto unit) {                               // the whole pass, once per kind of reference level
+            auto level = [&](float s) -> float {
+                if (!DB) return s;
+                const float c = fmaxf(s, D.amin);
+                return fmaxf(D.coef * log10f(decltype(unit)::value ? c : c / ref), floor_v);
+            };
+            for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+                const int64_t o = e / inner, i = e - o * inner;
+                const off_t xo = (off_t)(o * n_in * inner + i), oo = (off_t)(o * n_out * inner + i);
+                float acc[KT];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) acc[k] = 0.0f;
-            for (int m0 = 0; m0 < n_in; m0 += 8) {
-                float v[8];
+                for (int k = 0; k < KT; ++k) acc[k] = 0.0f;
+                const float *row = x;                               // row m of every clip, wave-uniform
+                auto load8 = [&](float (&d)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = m0 + j < n_in ? xp[(int64_t)(m0 + j) * inner] : 0.0f;
+                    for (int j = 0; j < 8; ++j) d[j] = (row + j * inner)[xo];
+                    row += 8 * inner;
+                };
+                auto use8 = [&](const float (&d)[8], int m) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (m0 + j < n_in) {
-                        const float vv = DB ? fmaxf(ap_db_value(D, ref, v[j]), floor_v) : v[j];
-                        const float *c = Ct + (m0 + j) * KT;
+                    for (int j = 0; j < 8; ++j) {
+                        const float vv = level(d[j]);
+                        const float *c = Ct + (m + j) * KT;
 #pragma unroll
                         for (int k = 0; k < KT; ++k) acc[k] = fmaf(c[k], vv, acc[k]);
                     }
+                };
+                // groups of 8 rows, the loads of the next group in flight under the arithmetic of this one
+                const int groups = n_in >> 3;
+                float cur[8], nxt[8];
+                if (groups) load8(cur);
+#pragma nounroll
+                for (int g = 0; g < groups; ++g) {
+                    if (g + 1 < groups) load8(nxt);
+                    use8(cur, 8 * g);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+                }
+                for (int m0 = 8 * groups; m0 < n_in; ++m0) {
+                    const float vv = level(row[xo]);
+                    row += inner;
+                    const float *c = Ct + m0 * KT;
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) acc[k] = fmaf(c[k], vv, acc[k]);
+                }
+                float *orow = out + (int64_t)k0 * inner;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    if (k0 + k < n_out) orow[oo] = row_scale ? acc[k] * row_scale[k0 + k] : acc[k];
+                    orow += inner;
                 }
             }
-#pragma unroll
-            for (int k = 0; k < KT; ++k)
-                if (k0 + k < n_out)
-                    op[(int64_t)(k0 + k) * inner] = row_scale ? acc[k] * row_scale[k0 + k] : acc[k];
-        }
+        };
+        if (unit_ref) sweep(std::true_type{});
+        else sweep(std::false_type{});
     }
 }
 

@@ -232,8 +232,10 @@ def to_db(S, coef=10.0, amin=1e-10, ref=1.0, ref_is_max=False, top_db=80.0):
     return out
 
 
-def dct(x, C, outer, n_in, inner, row_scale=None, db=None):
-    """db = (coef, amin, ref_value, top_db or None): fused power_to_db + DCT (ap_db_dct_f32)."""
+def dct(x, C, outer, n_in, inner, row_scale=None, db=None, wide=False):
+    """db = (coef, amin, ref_value, top_db or None): fused power_to_db + DCT (ap_db_dct_f32);
+    wide: the 64-bit-offset instantiation (tensors of 2^31 elements and more on the device)."""
+    lib().emu_set_dct_wide(int(wide))
     x = np.ascontiguousarray(x, np.float32)
     C = np.ascontiguousarray(C, np.float32)
     n_out = C.shape[0]

@@ -415,6 +415,9 @@ int emu_to_db_f32(const float *S, int64_t n, float coef, float amin, float ref_v
 }
 
 // db = 1: fused power_to_db (ref_value, amin, top_db) + DCT, like ap_db_dct_f32
+static int emu_dct_wide = 0;      // 1: the 64-bit-offset instantiation of ap_dct_kernel
+void emu_set_dct_wide(int on) { emu_dct_wide = on; }
+
 int emu_dct_f32(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
                 int64_t inner, int n_out, int db, float coef, float amin, float ref_value, float top_db,
                 float *out) {
@@ -434,10 +437,16 @@ int emu_dct_f32(const float *x, const float *C, const float *row_scale, int64_t 
         else emu_launch(grid, AP_BLOCK, [&] { ap_dct_generic_kernel<32>(x, C, row_scale, outer, n_in, inner, n_out, out); });
         return AP_OK;
     }
-    if (KT == 16 && db) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<16, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
-    else if (KT == 16) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<16, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
-    else if (db) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
-    else emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<32, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out); });
+#define EMU_DCT(KTV, DBV) \
+    do { \
+        if (emu_dct_wide) emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<KTV, DBV, 1>(x, C, row_scale, outer, n_in, inner, n_out, D, out); }); \
+        else emu_launch(grid, AP_BLOCK, [&] { ap_dct_kernel<KTV, DBV, 0>(x, C, row_scale, outer, n_in, inner, n_out, D, out); }); \
+    } while (0)
+    if (KT == 16 && db) EMU_DCT(16, 1);
+    else if (KT == 16) EMU_DCT(16, 0);
+    else if (db) EMU_DCT(32, 1);
+    else EMU_DCT(32, 0);
+#undef EMU_DCT
     return AP_OK;
 }
 

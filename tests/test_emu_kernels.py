@@ -282,6 +282,16 @@ def test_emu_db_dct_and_gl_projection():
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
     got = eb.dct(x, ao.dct_matrix(24, 40), 3, 40, 50).reshape(3, 24, 50)       # 32-wide chunks
     np.testing.assert_allclose(got, ao.dct(x, n=24, axis=1), rtol=1e-4, atol=1e-4)
+    # both offset widths are the same arithmetic; a reference level other than 1 takes the division;
+    # row counts that are not a multiple of the 8-row load group take the remainder loop
+    for wide in (False, True):
+        for n_in, n_out in ((40, 13), (43, 13), (7, 7), (45, 24)):
+            Sx = (rng.standard_normal((2, n_in, 33)).astype(np.float32)) ** 2
+            Cx = ao.dct_matrix(n_out, n_in)
+            np.testing.assert_array_equal(eb.dct(Sx, Cx, 2, n_in, 33, wide=wide), eb.dct(Sx, Cx, 2, n_in, 33))
+            got = eb.dct(Sx, Cx, 2, n_in, 33, db=(10.0, 1e-10, 0.37, 60.0), wide=wide).reshape(2, n_out, 33)
+            want = ao.dct(ao.power_to_db(Sx, ref=0.37, top_db=60.0), n=n_out, axis=1)
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)
     # Griffin-Lim projection: init and one momentum step, with a shorter R (zero-padded frames)
     Sm = np.abs(rng.standard_normal((2, 9, 7))).astype(np.float32)
     ang = rng.uniform(-np.pi, np.pi, Sm.shape).astype(np.float32)

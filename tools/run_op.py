@@ -1,5 +1,5 @@
 """Run one operator a few times on the headline-sized batch (for rocprofv3 passes).
-usage: python3 tools/run_op.py {stft|istft|mel|mel1024|mel512|stft512|whisper|gl|mfcc|resample|resfft|reslin} [reps]"""
+usage: python3 tools/run_op.py {stft|istft|mel|mfcc400|mel1024|mel512|stft512|whisper|gl|mfcc|resample|resfft|reslin} [reps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,9 @@ elif op == "resample":
 elif op == "mfcc":
     y = torch.randn((1024, 160000), device="cuda", generator=g) * 0.1
     fn = lambda: ap.mfcc(y, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+elif op == "mfcc400":
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    fn = lambda: ap.mfcc(y, sr=16000, n_mfcc=13, n_fft=400, hop_length=160, n_mels=80)
 elif op == "mel1024":
     y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
     fn = lambda: ap.melspectrogram(y, sr=22050, n_fft=1024, hop_length=256, n_mels=80)
