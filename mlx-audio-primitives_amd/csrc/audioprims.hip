@@ -677,8 +677,9 @@ template <int KT, int DB, int WIDE>
 static int ap_launch_dct_as(const float *x, const float *C, const float *row_scale, int64_t outer, int n_in,
                             int64_t inner, int n_out, const ApDbParams &D, float *out, void *stream, int lds) {
     const int grid = ap_grid_1d(outer * inner, AP_BLOCK, kApStreamGrid);
-    // 16 outputs: five workgroups per CU (<= 96 VGPRs); the pass waits on its row loads, so the fifth wave
-    // per SIMD is worth more than the handful of spilled words (mfcc tail of config 4: 59.9 -> 55.4 us)
+    // 16 outputs: held to five waves per SIMD (<= 96 VGPRs; HIP's second launch-bound is waves per SIMD); the pass
+    // waits on its row loads, so the fifth wave is worth more than the handful of spilled words (mfcc tail of
+    // config 4: 59.9 -> 55.4 us)
     constexpr int MINB = KT == 16 ? 5 : 1;
     int rc = ap_allow_lds(ap_dct_kernel<KT, DB, WIDE, MINB>, lds);
     if (rc != AP_OK) return rc;
