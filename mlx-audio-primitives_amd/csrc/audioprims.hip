@@ -944,8 +944,12 @@ int ap_preemphasis_f32(const float *y, int64_t B, int64_t L, float coef, const f
     if (!y || !out) AP_FAIL(AP_ERR_INVALID, "preemphasis: NULL buffer");
     if (!(coef >= 0.0f && coef <= 1.0f)) AP_FAIL(AP_ERR_INVALID, "coef must be in [0, 1], got %g", (double)coef);
     if (B <= 0 || L <= 0) AP_FAIL(AP_ERR_INVALID, "preemphasis: signal must be non-empty");
-    hipLaunchKernelGGL(ap_preemphasis_kernel, dim3(ap_grid_1d(B * L, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
-                       (hipStream_t)stream, y, B, L, coef, zi, out, zf);
+    if (L % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+        hipLaunchKernelGGL(ap_preemphasis4_kernel, dim3(ap_grid_1d(B * L / 4, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                           (hipStream_t)stream, y, B, L, coef, zi, out, zf);
+    else
+        hipLaunchKernelGGL(ap_preemphasis_kernel, dim3(ap_grid_1d(B * L, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                           (hipStream_t)stream, y, B, L, coef, zi, out, zf);
     return ap_check_launch("ap_preemphasis_f32");
 }
 

@@ -228,7 +228,9 @@ def test_frame_api(random_signal, batch_signals):
 # ------------------------------------------------------------------ pre- / de-emphasis
 @pytest.mark.parametrize("coef", [0.97, 0.5, 0.0, 1.0])
 def test_preemphasis_deemphasis(random_signal, batch_signals, coef):
-    for sig in (random_signal, batch_signals, random_signal[:5], random_signal[:4097]):
+    # 22 050 / 5 / 4 097 samples: the one-sample kernel; 4 096 / 22 048 (x 3 clips): the 16-byte kernel
+    for sig in (random_signal, batch_signals, random_signal[:5], random_signal[:4097], random_signal[:4096],
+                np.ascontiguousarray(batch_signals[:3, :22048])):
         p, zf = ap.preemphasis(dev(sig), coef=coef, return_zf=True)
         pw, zfw = ao.preemphasis(sig, coef=coef, return_zf=True)
         np.testing.assert_allclose(host(p), pw, rtol=1e-6, atol=1e-6)
