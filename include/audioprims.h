@@ -135,6 +135,16 @@ int ap_stft_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop
                 const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
                 int64_t T, float *out /*dev (B,F,T,2)*/, void *stream);
 
+/* The same with the rows of `out` `row_stride` complex values apart (row_stride >= T; the (B, F, T)
+ * result is then a strided view of a (B, F, row_stride) buffer and the columns T..row_stride-1 are
+ * never written).  With row_stride a multiple of 16 and a 128-byte aligned `out` every group of 16
+ * frames leaves as whole 128-byte lines - the workspace layout of the Griffin-Lim loop
+ * (griffinlim.py:129-180), where the spectra never leave the library.  No reference counterpart:
+ * mx.fft.rfft + transpose (stft.py:130,216) always yields the dense layout, which is row_stride = T. */
+int ap_stft_rows_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop,
+                     const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
+                     int64_t T, int64_t row_stride, float *out /*dev (B,F,row_stride,2)*/, void *stream);
+
 /* Mel contraction plan.  The filterbank is tiny and built on the host (mel.py:100-168),
  * so its sparsity is analysed on the host once and shipped to the device next to it.
  * ap_mel_plan_host fills a device-bound blob `plan` (int32 words, copy it to HBM) and a
@@ -206,6 +216,13 @@ int ap_istft_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, int n_f
                  const float *window /*dev*/, const float *tw /*dev*/, float *frames_ws /*dev*/,
                  int64_t out_offset, int64_t out_len, float *out /*dev (B,out_len)*/,
                  void *stream);
+
+/* The same from a spectrum whose rows are `row_stride` complex values apart (the layout ap_stft_rows_f32
+ * writes; row_stride == T is the dense layout).  n_fft = 2048 with hop in {256, 512, 1024} only (the fused
+ * kernel: no workspace); AP_ERR_UNSUPPORTED otherwise - copy to a dense array and call ap_istft_f32. */
+int ap_istft_rows_f32(const float *S /*dev (B,F,row_stride,2)*/, int64_t B, int64_t T, int64_t row_stride,
+                      int n_fft, int hop, const float *window /*dev*/, const float *tw /*dev*/,
+                      int64_t out_offset, int64_t out_len, float *out /*dev (B,out_len)*/, void *stream);
 
 /* resample_poly core: x (B,L) -> out (B, n_out), n_out = ceil(L*up/down),
  *   out[b,o] = sum_i taps[t - up*i] * x[b,i],  t = (o + n_pre_remove)*down,

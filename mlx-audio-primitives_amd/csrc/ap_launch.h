@@ -627,6 +627,75 @@ static inline int ap_prepare_stft_wave(ApStftWaveParams &W, const ApStftParams &
     return AP_OK;
 }
 
+// n_fft = 2048 STFT, 16 frames per group (kernels_stft16.h).  Ts = complex values between the rows of
+// `out` (T for the reference's contiguous layout); *aligned = 1 when every group's row segment is a
+// whole 128-byte line (Ts a multiple of 16 and a 128-byte aligned base): the kernel then needs no carries.
+static inline int ap_prepare_stft16(ApStft16Params &W, const ApStftParams &P, int64_t B, int64_t Ts, int *grid,
+                                    int *aligned) {
+    if (P.L > (1 << 28)) return 1;                        // 32-bit sample offsets in the bounds-checked loads
+    if (Ts < P.T) return 1;
+    W.y = P.y;
+    W.window = P.window;
+    W.tw = P.tw;
+    W.out = P.out_c;
+    W.L = P.L;
+    W.T = P.T;
+    W.Ts = Ts;
+    W.groups_per_clip = (P.T + APS16_G - 1) / APS16_G;
+    W.n_groups = W.groups_per_clip * B;
+    W.hop = P.hop;
+    W.pad = P.pad;
+    W.pad_mode = P.pad_mode;
+    int off = APS_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
+    W.off_ob = off; off += ap_align16(2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2));
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    if (Ts > (1 << 20)) return 1;                         // 32-bit row offsets (1024 Ts complex) in the store phase
+    W.stagger = 0;
+    *aligned = (Ts % APS16_G == 0 && (reinterpret_cast<uintptr_t>(P.out_c) & 127) == 0) ? 1 : 0;
+    int64_t g = W.n_groups < 256 ? W.n_groups : 256;      // persistent: one workgroup per CU
+    *grid = (int)g;
+    return AP_OK;
+}
+
+// n_fft = 2048 fused ISTFT with 16-frame loads (kernels_istft16.h).  Ts = complex values between the rows of S.
+// Returns 1 when the kernel does not apply (shape, LDS).
+static inline int ap_prepare_istft16(ApIstft16Params &W, const float *S, const float *tw, int64_t B, int64_t T,
+                                     int64_t Ts, const float *window, int hop, int64_t out_offset, int64_t out_len,
+                                     float *y, int *grid) {
+    if (B <= 0 || T <= 0 || Ts < T || Ts > (1 << 20)) return 1;       // 32-bit row offsets (1024 Ts complex)
+    if (hop < 256 || hop > 2048 || 2048 % hop != 0) return 1;
+    if (out_offset % 4 != 0) return 1;
+    W.S = reinterpret_cast<const ap_float2 *>(S);
+    W.tw = reinterpret_cast<const ap_float2 *>(tw);
+    W.window = window;
+    W.y = y;
+    W.T = T;
+    W.Ts = Ts;
+    W.g16_per_clip = (T + APS16_G - 1) / APS16_G;
+    W.n_g16 = W.g16_per_clip * B;
+    W.out_offset = out_offset;
+    W.out_len = out_len;
+    W.hop = hop;
+    int off = APS_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
+    W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
+    W.off_win = off; off += 2048 * (int)sizeof(float);
+    W.off_ib = off; off += ap_align16(2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2));
+    W.off_carry = off; off += 2 * (2048 - hop) * (int)sizeof(float);
+    W.lds_bytes = off;
+    if (off > AP_LDS_MAX) return 1;
+    // persistent, one workgroup per CU; a stretch that starts inside a clip re-runs 8 frames, so >= 2 groups each
+    int64_t g = W.n_g16 / 2;
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return AP_OK;
+}
+
 // One leg of the four-step transform.
 static inline int ap_prepare_cfft_leg(ApCfftParams &C, int n, int64_t n_frames, int64_t B) {
     if (ap_make_cplan(n, &C.plan) != 0) AP_FAIL(AP_ERR_UNSUPPORTED, "cfft: cannot plan length %d", n);

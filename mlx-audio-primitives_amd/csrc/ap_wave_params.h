@@ -61,6 +61,34 @@ struct ApStftWaveParams {
     int off_tw2, off_tw1, off_win, off_ob, lds_bytes;
 };
 
+// ---- n_fft = 2048 STFT, 16 frames per group (kernels_stft16.h) -------------------------------
+// Every wave transforms TWO frames of a 16-frame group; rows of (B, F, T) leave as 128-byte windows.
+#define APS16_G 16           // frames per group = complex values per 128-byte row window
+#define APS16_OB_ROW 17      // complex slots per row of the transpose buffer (16 frames + 1 pad)
+#define APS16_OB_ROWS 129    // rows per chunk: 64 bins + 64 mirrored bins (+ bin 512 in the last chunk)
+
+struct ApStft16Params {
+    const float *y;            // (B, L)
+    const float *window;       // (2048)
+    const ap_float2 *tw;       // (2048)
+    ap_float2 *out;            // (B, 1025, T) with rows `Ts` complex values apart
+    int64_t L, T, Ts, groups_per_clip, n_groups;
+    int hop, pad, pad_mode;
+    int off_tw2, off_tw1, off_win, off_ob, lds_bytes;
+    int stagger;               // start-up delay of workgroup i: ((i / 8) % 4) * stagger * 64 * 127 cycles (see the kernel)
+};
+
+// ---- n_fft = 2048 fused ISTFT, 16-frame loads (kernels_istft16.h) ---------------------------
+struct ApIstft16Params {
+    const ap_float2 *S;        // (B, 1025, T), rows Ts complex apart
+    const ap_float2 *tw;       // (2048)
+    const float *window;       // (2048) synthesis window
+    float *y;                  // (B, out_len)
+    int64_t T, Ts, g16_per_clip, n_g16, out_offset, out_len;
+    int hop;                   // 2048 % hop == 0, hop >= 256
+    int off_tw2, off_tw1, off_win, off_ib, off_carry, lds_bytes;
+};
+
 struct ApIrfftWaveParams {
     const ap_float2 *S;        // (B, 1025, T)
     const ap_float2 *tw;       // (2048)

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "ap_launch.h"
+#include "ap_tu.h"
 #include "kernels_generic.h"
 #include "kernels_wave.h"
 #include "kernels_pointwise.h"
@@ -243,6 +244,13 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
     if (!out) AP_FAIL(AP_ERR_INVALID, "stft: NULL output");
     P.out_c = reinterpret_cast<ap_float2 *>(out);
     if (n_fft == 2048) {
+        // 16 frames per group: rows leave as 128-byte line-aligned windows (kernels_stft16.h);
+        // AP_STFT2048_G8=1 keeps the 8-frame kernel of rounds 1-2 for A/B measurements
+        static const bool g8 = std::getenv("AP_STFT2048_G8") != nullptr;
+        if (!g8) {
+            rc = ap_launch_stft16(P, B, T, stream);
+            if (rc != 1) return rc;
+        }
         ApStftWaveParams W;
         int grid = 0;
         if (ap_prepare_stft_wave(W, P, B, &grid) == AP_OK) {
@@ -292,6 +300,22 @@ int ap_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const 
     hipLaunchKernelGGL(ap_stft_generic_kernel<0>, dim3((unsigned)(P.tiles_per_clip * B)),
                        dim3(AP_BLOCK), P.tile.lds_bytes, (hipStream_t)stream, P);
     return ap_check_launch("ap_stft_f32");
+}
+
+int ap_stft_rows_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                     const float *tw, int center, int pad_mode, int64_t T, int64_t row_stride, float *out, void *stream) {
+    if (row_stride == T) return ap_stft_f32(y, B, L, n_fft, hop, window, tw, center, pad_mode, T, out, stream);
+    if (row_stride < T) AP_FAIL(AP_ERR_INVALID, "stft: row_stride (%lld) must be >= the number of frames (%lld)",
+                                (long long)row_stride, (long long)T);
+    if (n_fft != 2048) AP_FAIL(AP_ERR_UNSUPPORTED, "stft: padded rows are served for n_fft = 2048 only");
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
+    if (rc != AP_OK) return rc;
+    if (!out) AP_FAIL(AP_ERR_INVALID, "stft: NULL output");
+    P.out_c = reinterpret_cast<ap_float2 *>(out);
+    rc = ap_launch_stft16(P, B, row_stride, stream);
+    if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "stft: shape not served with padded rows");
+    return rc;
 }
 
 int ap_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
@@ -430,6 +454,14 @@ int64_t ap_istft_workspace_floats(int64_t B, int64_t T, int n_fft, int hop, int6
 int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const float *window,
                  const float *tw, float *frames_ws, int64_t out_offset, int64_t out_len, float *out,
                  void *stream) {
+    if (n_fft == 2048 && S && tw && window && out && hop > 0 && out_len > 0 && ap_istft_fused_shape(B, T, 2048, hop, out_offset)) {
+        // 16-frame loads (kernels_istft16.h); AP_ISTFT2048_G8=1 keeps the 8-frame kernel of rounds 1-2 for A/B runs
+        static const bool g8 = std::getenv("AP_ISTFT2048_G8") != nullptr;
+        if (!g8) {
+            const int rc16 = ap_launch_istft16(S, tw, B, T, T, window, hop, out_offset, out_len, out, stream);
+            if (rc16 != 1) return rc16;
+        }
+    }
     if (n_fft == 2048 && window && out && hop > 0 && out_len > 0) {
         // fused irfft + overlap-add: the (B, T, n_fft) frames never reach HBM
         ApIrfftParams P;
@@ -473,6 +505,17 @@ int ap_istft_f32(const float *S, int64_t B, int64_t T, int n_fft, int hop, const
     int rc = ap_irfft_frames_f32(S, B, T, n_fft, tw, frames_ws, stream);
     if (rc != AP_OK) return rc;
     return ap_overlap_add_f32(frames_ws, window, B, T, n_fft, hop, out_offset, out_len, out, stream);
+}
+
+int ap_istft_rows_f32(const float *S, int64_t B, int64_t T, int64_t row_stride, int n_fft, int hop, const float *window,
+                      const float *tw, int64_t out_offset, int64_t out_len, float *out, void *stream) {
+    if (!S || !tw || !window || !out) AP_FAIL(AP_ERR_INVALID, "istft: NULL buffer");
+    if (row_stride < T) AP_FAIL(AP_ERR_INVALID, "istft: row_stride (%lld) must be >= the number of frames (%lld)",
+                                (long long)row_stride, (long long)T);
+    if (n_fft != 2048 || hop <= 0 || out_len <= 0) AP_FAIL(AP_ERR_UNSUPPORTED, "istft: padded rows are served for n_fft = 2048 only");
+    const int rc = ap_launch_istft16(S, tw, B, T, row_stride, window, hop, out_offset, out_len, out, stream);
+    if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "istft: shape not served with padded rows (hop must divide 2048, hop >= 256)");
+    return rc;
 }
 
 // kept outputs [n_pre_remove, n_pre_remove + n_out) of upfirdn(taps, x, up, down) with zeros outside x

@@ -8,6 +8,13 @@
 // (stft.py:216), mx.abs/mx.power/mx.matmul (mel.py:321-350), mx.fft.irfft
 // (stft.py:295) and overlap_add.metal:16-55.
 #pragma once
+// Non-template kernels of this header: one translation unit owns them with external linkage; every
+// other unit that includes the header for its device helpers (AP_TU_SECONDARY) gets private copies.
+#ifdef AP_TU_SECONDARY
+#define AP_KERNEL static __global__
+#else
+#define AP_KERNEL __global__
+#endif
 #include "fft_lds.h"
 
 #ifndef AP_PAD_CONSTANT
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_stft_generic_kernel(ApStftParams 
 
 // irfft of each frame: S (B,F,T) -> frames (B,T,n).  Inverse via the forward
 // engine on conjugated data.
-__global__ void __launch_bounds__(AP_BLOCK) ap_irfft_generic_kernel(ApIrfftParams P) {
+AP_KERNEL void __launch_bounds__(AP_BLOCK) ap_irfft_generic_kernel(ApIrfftParams P) {
     const ApFftPlan &pl = P.plan;
     const int G = P.tile.G, fstride = P.tile.fstride, nc = pl.nc, n = pl.n;
     ap_float2 *bufA = reinterpret_cast<ap_float2 *>(ap_smem);
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(AP_BLOCK) ap_irfft_generic_kernel(ApIrfftParam
 }
 
 // overlap_add.metal:16-55 with an output offset (folds istft's centre trim).
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_overlap_add_kernel(const float *frames, const float *window, int64_t T, int n_fft, int hop,
                       int64_t out_offset, int64_t out_len, int64_t blocks_per_row, float *out) {
     const int64_t bid = blockIdx.x;
@@ -203,7 +210,7 @@ ap_overlap_add_kernel(const float *frames, const float *window, int64_t T, int n
     out[b * out_len + i] = sum / fmaxf(wss, 1e-8f);
 }
 
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_pad_kernel(const float *x, int64_t B, int64_t L, int64_t pad, int mode, float *out) {
     const int64_t Lo = L + 2 * pad;
     const int64_t total = B * Lo;
@@ -215,7 +222,7 @@ ap_pad_kernel(const float *x, int64_t B, int64_t L, int64_t pad, int mode, float
     }
 }
 
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_frame_kernel(const float *x, int64_t B, int64_t L, int64_t T, int frame_length, int hop,
                 float *out) {
     const int64_t total = B * T * frame_length;
@@ -230,7 +237,7 @@ ap_frame_kernel(const float *x, int64_t B, int64_t L, int64_t T, int frame_lengt
 }
 
 // mode 0: |S| (mx.abs, stft.py:362)   mode 1: atan2(im, re) (stft.py:379)
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_complex_unary_kernel(const ap_float2 *S, int64_t n, int mode, float *out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
@@ -241,7 +248,7 @@ ap_complex_unary_kernel(const ap_float2 *S, int64_t n, int mode, float *out) {
 
 // scipy.signal.resample_poly (upfirdn, zero padding) — reference resample.py:279-281.
 // One thread per output sample; float32 accumulation in increasing input index.
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_resample_poly_kernel(const float *x, int64_t L, int up, int down, const float *taps, int n_taps,
                         int n_pre_remove, int64_t n_out, int64_t blocks_per_row, float *out) {
 #ifndef AP_HOST_EMU
@@ -269,7 +276,7 @@ ap_resample_poly_kernel(const float *x, int64_t L, int up, int down, const float
 // sum_k hp[ph][k] x[i - k], accumulated from the largest k down = increasing input index, the product
 // rounded before the sum: the order and roundings of SciPy's loop, so still bit-exact.
 #define AP_RSPL_R 4
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_resample_poly_lds_kernel(const float *x, int64_t L, int up, int down, const float *taps, int n_taps,
                             int n_pre_remove, int64_t n_out, int64_t blocks_per_row, int K, int KS, int span,
                             float *out) {
@@ -415,7 +422,7 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
 }
 
 // reference resample.py:183-195: float64 positions and interpolation, float32 result
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_resample_linear_kernel(const float *x, int64_t B, int64_t L, int64_t n_out, double scale, float *out) {
     const int64_t total = B * n_out;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -1,0 +1,239 @@
+// Fused ISTFT, n_fft = 2048, hop 256 / 512 / 1024: S (B, 1025, T) complex with rows `Ts` apart -> y (B, out_len)
+// (transpose + mx.fft.irfft + overlap-add + trim, stft.py:292-338; overlap_add.metal:16-55) — round 3.
+//
+// The transform and the overlap-add are those of ap_irfft2048_wave_kernel<1> (kernels_wave.h: one frame per
+// wave, 8 frames per step, the windowed frames gathered out of the waves' LDS buffers with a carry along the
+// workgroup's contiguous stretch); what is new is how the spectrum comes in.  tools/load_probe.hip
+// (profiles/r03_load_probe.txt) showed that for LOADS of this layout the alignment of a row segment does not
+// matter and its length does (8 frames = 64 bytes: every 128-byte line is requested twice; FETCH_SIZE of the
+// 8-frame kernel was 1.72 x the spectrum even with its sector-aligned windows and their 68 carry registers).  So a
+// workgroup loads 16 FRAMES of every row at once, as they fall (16 lanes x 8 bytes = one or two lines, whole
+// lines for the padded-row layout ap_stft_rows_f32 writes), one 16-frame group ahead of its use, stages them
+// through LDS in 8 chunks of 128 bins so that every wave ends up with the bins of its TWO frames (t0 + w now,
+// t0 + 8 + w kept in registers for the second step), and runs two 8-frame steps per load.
+#pragma once
+#include "kernels_wave.h"
+
+
+__global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApIstft16Params P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    ap_float2 *IB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ib);        // [2][129][17]
+    {
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        if (tid < 64)       // signs of the quad stage folded in, as in apw_fill_tables
+            tw2[(tid >> 4) * 17 + (tid & 15)] = ap_scale(P.tw[32 * (tid >> 4) * (tid & 15)], ((tid >> 4) == 1 || (tid >> 4) == 2) ? -1.0f : 1.0f);
+        for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
+        float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
+        for (int i = tid; i < 2 * APW_NC; i += 64 * APS_WAVES) win[i] = P.window[i];
+    }
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    AP_LDS_BARRIER();
+    const int F = APW_NC + 1;
+    const float scale = 1.0f / 1024.0f;    // 1/n_fft, and the merge below works at half scale
+    const int Ti = (int)P.T, Ts = (int)P.Ts;
+
+    const int64_t g_lo = P.n_g16 * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_hi = P.n_g16 * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (g_lo >= g_hi) return;
+    // loader role: thread (sq = tid / 16, sf = tid % 16) fetches frame t0 + sf of the rows sq, 32 + sq (bins
+    // 64 c + l) and 64 + sq, 96 + sq (bins 1024 - 64 c - l) of every chunk c, + bin 512 by the first 16 threads
+    const int sq0 = tid >> 4, sf0 = tid & 15;
+    ap_float2 pre[8][4], pre_mid = ap_mk(0.0f, 0.0f);
+    // (32-bit arithmetic: the launch code bounds Ts by 2^20, so bin Ts + t < 2^31)
+    // chunk c of the 16-frame group g16 -> pre[c] (c == 7: + bin 512)
+    auto load_chunk = [&](int64_t g16, int c) {
+        int sq = sq0, sf = sf0;
+        AP_PIN(sq);                          // row offsets recomputed per use, not hoisted into 33 live registers
+        AP_PIN(sf);
+        const int64_t b = g16 / P.g16_per_clip;
+        const int t = (int)((g16 - b * P.g16_per_clip) * APS16_G) + sf;
+        const ap_float2 *sb = P.S + b * (int64_t)F * P.Ts;
+        const bool ok = t < Ti;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = sq + 32 * (i & 1);
+            const int bin = (i >> 1) ? APW_NC - 64 * c - l : 64 * c + l;
+            pre[c][i] = ok ? sb[bin * Ts + t] : ap_mk(0.0f, 0.0f);
+        }
+        if (c == 7 && tid < APS16_G) pre_mid = ok ? sb[(APW_NC / 2) * Ts + t] : ap_mk(0.0f, 0.0f);
+    };
+    auto load16 = [&](int64_t g16) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) load_chunk(g16, c);
+    };
+    // pre -> LDS -> every wave's bins of its two frames: xk[r] = S[64 r + lane], xm[r] = S[1024 - 64 r - lane]
+    // `next16 >= 0`: as soon as chunk c has left its registers, the loads of chunk c of that group are issued
+    // into them: they have a whole period (two transforms and two gathers) to land, and the bursts of the 256
+    // workgroups (131 KB each) do not have to be served inside one gather.
+    auto stage = [&](ap_float2 (&xkA)[8], ap_float2 (&xmA)[8], ap_float2 &xhA, ap_float2 (&xkB)[8], ap_float2 (&xmB)[8],
+                     ap_float2 &xhB, int64_t next16) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ap_float2 *buf = IB + (c & 1) * (APS16_OB_ROWS * APS16_OB_ROW);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                buf[((i >> 1) * 64 + sq0 + 32 * (i & 1)) * APS16_OB_ROW + sf0] = pre[c][i];
+            if (c == 7 && tid < APS16_G) buf[128 * APS16_OB_ROW + sf0] = pre_mid;
+            AP_LDS_BARRIER();
+            if (next16 >= 0) load_chunk(next16, c);
+            xkA[c] = buf[lane * APS16_OB_ROW + wave];
+            xkB[c] = buf[lane * APS16_OB_ROW + 8 + wave];
+            xmA[c] = buf[(64 + lane) * APS16_OB_ROW + wave];
+            xmB[c] = buf[(64 + lane) * APS16_OB_ROW + 8 + wave];
+            if (c == 7) {
+                xhA = buf[128 * APS16_OB_ROW + wave];
+                xhB = buf[128 * APS16_OB_ROW + 8 + wave];
+            }
+        }
+    };
+
+    const int H = P.hop;
+    const int CN = 2 * APW_NC - H;                              // carry length
+    const int hs = H == 256 ? 8 : (H == 512 ? 9 : 10);           // H = 1 << hs
+    const ap_float2 *WINP = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // (w[2n], w[2n+1])
+    const float *WIN = reinterpret_cast<const float *>(ap_smem + P.off_win);
+    const float *XF = reinterpret_cast<const float *>(ap_smem);  // frame f at XF + f * 2 APW_X_COMPLEX
+    const int n_own = APS_WAVES * H;                             // positions one 8-frame step completes
+
+    // One 8-frame step: frames t0 .. t0 + 7 of clip b from the waves' (xk, xm, xh); `half` picks the carry
+    // buffers (steps alternate); `next16 >= 0`: issue the loads of that 16-frame group once xk / xm are consumed.
+    auto step = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 xh, int64_t b, int t0i, int half, bool emit) {
+        // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[1024-k]) / 2 of the packed inverse -----
+        //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = (W^-k / 2) d
+        //   conj Z[k] / 2 = conj(a/2 + i o),  conj Z[1024-k] / 2 = a/2 - i o
+        // the other waves may still be gathering the previous step's frames out of this wave's buffer (a
+        // first step is preceded by the barriers of the staging pass)
+        if (half) AP_LDS_BARRIER();
+        ap_float2 v[16];
+        ap_float2 tws0h = lc.tws0h;          // opaque per step: keeps the 8 merge twiddles out of loop-invariant registers
+        AP_PIN(tws0h.x);
+        AP_PIN(tws0h.y);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            ap_float2 a_k = xk[r], a_m = xm[r];
+            if (r == 0 && lane == 0) { a_k.y = 0.0f; a_m.y = 0.0f; }      // DC / Nyquist imaginary parts ignored
+            const ap_float2 a = ap_add_conj(a_k, a_m);
+            const ap_float2 d = ap_sub_conj(a_k, a_m);
+            const ap_float2 w = r == 0 ? tws0h : ap_mul_bw_c(tws0h, APW_C32(r), APW_S32(r));
+            const ap_float2 o = ap_mul_bw(d, w);                           // W^-k = (c, +s)
+            v[r] = ap_fma_sub_swap(a, lc.halfc, o);                         // index lane + 64 r
+            // index 1024 - k belongs to lane 64 - lane (register 15 - r): exchange through LDS
+            const int km = (APW_NC - (lane + 64 * r)) & (APW_NC - 1);
+            if (!(r == 0 && lane == 0)) X[apw_zidx(km)] = ap_fma_add_mi(a, lc.half, o);
+        }
+        if (lane == 0) X[apw_zidx(APW_NC / 2)] = xh;    // bin 512 pairs with itself: conj Z[512] / 2 = X[512]
+        AP_WAVE_SYNC();
+#pragma unroll
+        for (int j = 8; j < 16; ++j) v[j] = X[apw_zidx(lane + 64 * j)];
+        AP_WAVE_SYNC();
+        AP_SCHED_FENCE();
+        apw_forward<false, true>(v, X, TW1, lc);         // the register-lean form: 66 prefetch registers stay live
+        AP_SCHED_FENCE();
+        // ---- fused overlap-add ---------------------------------------------------------------
+        float *carry_in = reinterpret_cast<float *>(ap_smem + P.off_carry) + half * CN;
+        float *carry_out = reinterpret_cast<float *>(ap_smem + P.off_carry) + (half ^ 1) * CN;
+        {   // windowed frame -> this wave's exchange buffer (padded natural order: conflict-free)
+            ap_float2 wv[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) wv[cc] = WINP[lc.k1p + 16 * cc + 256 * lc.qd];
+            AP_WAVE_SYNC();                                          // quad stage done with X
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int n = lc.k1p + 16 * cc + 256 * lc.qd;
+                X[apw_zidx(n)] = ap_mul2(ap_mul2(v[cc], ap_mk(scale, -scale)), wv[cc]);
+            }
+        }
+        if (t0i == 0)                                                // a clip starts: nothing carried in
+            for (int i = tid; i < CN; i += 64 * APS_WAVES) carry_in[i] = 0.0f;
+        AP_LDS_BARRIER();
+        const bool clip_last = t0i + APS_WAVES >= Ti;
+        const int64_t p0 = (int64_t)t0i * H;                         // padded position of r = 0
+        float *yb = P.y + b * P.out_len;
+        const int64_t n0 = p0 - P.out_offset;                        // output index of r = 0
+        for (int r = 4 * tid; r < n_own + CN; r += 4 * 64 * APS_WAVES) {
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            if (r < CN) {
+                const ap_float4 c4 = *reinterpret_cast<const ap_float4 *>(carry_in + r);
+                s0 = c4.x; s1 = c4.y; s2 = c4.z; s3 = c4.w;
+            }
+            // frames of this step that cover r: f H <= r < f H + n_fft (arithmetic shifts floor)
+            const int f_cov = ((r - 2 * APW_NC) >> hs) + 1;          // first covering frame, may be < 0
+            const int f_lo = f_cov < 0 ? 0 : f_cov;
+            int f_hi = r >> hs;
+            if (f_hi > APS_WAVES - 1) f_hi = APS_WAVES - 1;
+            for (int f = f_lo; f <= f_hi; ++f) {
+                const int sidx = r - (f << hs);                      // sample index in frame f (multiple of 4)
+                const ap_float4 q = *reinterpret_cast<const ap_float4 *>(
+                    XF + f * (2 * APW_X_COMPLEX) + 2 * apw_zidx(sidx >> 1));
+                s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
+            }
+            if (r >= n_own) {                                        // contributions to the next step's range
+                ap_float4 c4; c4.x = s0; c4.y = s1; c4.z = s2; c4.w = s3;
+                *reinterpret_cast<ap_float4 *>(carry_out + (r - n_own)) = c4;
+            }
+            if (emit && (r < n_own || clip_last)) {
+                // window-sum-of-squares over the frames of the CLIP that cover the position
+                // (relative frame numbers; frames before this step count too)
+                int F_lo = f_cov < -t0i ? -t0i : f_cov;
+                int F_hi = r >> hs;
+                if (F_hi > Ti - 1 - t0i) F_hi = Ti - 1 - t0i;
+                float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, w3 = 0.0f;
+                for (int Fi = F_lo; Fi <= F_hi; ++Fi) {
+                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (r - Fi * H));
+                    w0 += w.x * w.x; w1 += w.y * w.y; w2 += w.z * w.z; w3 += w.w * w.w;
+                }
+                const int64_t n = n0 + r;
+                if (n >= 0 && n + 3 < P.out_len) {
+                    ap_float4 o4;
+                    o4.x = s0 / fmaxf(w0, 1e-8f);
+                    o4.y = s1 / fmaxf(w1, 1e-8f);
+                    o4.z = s2 / fmaxf(w2, 1e-8f);
+                    o4.w = s3 / fmaxf(w3, 1e-8f);
+                    if (((reinterpret_cast<uintptr_t>(yb + n)) & 15) == 0) {
+                        *reinterpret_cast<ap_float4 *>(yb + n) = o4;
+                    } else {
+                        yb[n] = o4.x; yb[n + 1] = o4.y; yb[n + 2] = o4.z; yb[n + 3] = o4.w;
+                    }
+                } else {
+                    if (n >= 0 && n < P.out_len) yb[n] = s0 / fmaxf(w0, 1e-8f);
+                    if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
+                    if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
+                    if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+                }
+            }
+        }
+        if (emit && clip_last) {                                     // no frame reaches beyond the tail: 0 / 1e-8
+            int64_t n = p0 + n_own + CN - P.out_offset;
+            if (n < 0) n = 0;
+            for (n += tid; n < P.out_len; n += 64 * APS_WAVES) yb[n] = 0.0f;
+        }
+    };
+
+    ap_float2 xkA[8], xmA[8], xhA, xkB[8], xmB[8], xhB;
+    // A stretch that starts inside a clip first re-runs the 8 frames before it with the stores disabled: they
+    // rebuild the carry (its length 2048 - hop is at most 7 frames for hop >= 256).
+    if (g_lo % P.g16_per_clip != 0) {
+        load16(g_lo - 1);
+        stage(xkA, xmA, xhA, xkB, xmB, xhB, g_lo);
+        const int64_t b = (g_lo - 1) / P.g16_per_clip;
+        const int t0 = (int)((g_lo - 1 - b * P.g16_per_clip) * APS16_G);
+        step(xkB, xmB, xhB, b, t0 + 8, 1, false);
+    } else {
+        load16(g_lo);
+    }
+    for (int64_t g16 = g_lo; g16 < g_hi; ++g16) {
+        const int64_t b = g16 / P.g16_per_clip;
+        const int t0 = (int)((g16 - b * P.g16_per_clip) * APS16_G);
+        stage(xkA, xmA, xhA, xkB, xmB, xhB, g16 + 1 < g_hi ? g16 + 1 : -1);
+        step(xkA, xmA, xhA, b, t0, 0, true);
+        // the second step only exists when the clip has frames there; its carry parity continues either way
+        // (a clip that ends after the first step starts the next one with a zeroed carry_in of parity 0)
+        if (t0 + 8 < Ti) step(xkB, xmB, xhB, b, t0 + 8, 1, true);
+    }
+}

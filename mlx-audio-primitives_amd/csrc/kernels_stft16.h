@@ -1,0 +1,227 @@
+// STFT, n_fft = 2048, complex output (B, 1025, T) with T fastest (stft.py:216) — 16 frames per group.
+//
+// Round 3.  tools/store_probe.hip (profiles/r03_store_probe.txt) measured what the row segments of
+// this layout cost on MI355X, store-only, 905 MB: 64-byte segments as they fall 1.5 TB/s, 64-byte
+// sector-aligned windows 3.1 TB/s (what ap_stft2048_wave_kernel emits), 128-byte LINE-aligned windows
+// 4.1 TB/s (4.5 non-temporal), longer windows no better; a misaligned 128-byte segment 1.9 TB/s.  So a
+// row has to leave as whole aligned 128-byte lines = 16 frames.
+//
+// The 8 waves of a workgroup transform 16 CONSECUTIVE frames, two each (wave w: frames t0 + w and
+// t0 + 8 + w; the first one's spectrum waits in registers while the second is transformed with the
+// same register / LDS transform as kernels_wave.h), then transpose through LDS in 8 double-buffered
+// chunks of 128 bins x 16 frames (one LDS-only barrier per chunk) so that 16 adjacent lanes write the
+// 128 contiguous bytes of one bin's row.
+//
+// ALIGNED = 0 (the reference's contiguous layout, row stride T): rows start at arbitrary 8-byte
+// offsets, so row k is written in line-ALIGNED windows that lag the group by 16 - phi(k) frames,
+// phi(k) = frames from t0 to the row's next 128-byte boundary: the thread that owns position j of a
+// row's window keeps the not yet written frame of the previous group in a register ("carry", 33
+// complex per thread), the workgroup walks a contiguous stretch of one clip's groups so the window
+// is completed one group later by the same thread, and the carries are flushed at the end of a clip
+// / of the stretch (the scheme of ap_stft2048_wave_kernel at twice the window).
+// ALIGNED = 1 (row stride a multiple of 16 complex and a 128-byte aligned base: the workspace layout
+// of the Griffin-Lim loop): every group's segment is a whole line, no carries.
+#pragma once
+#include "kernels_wave.h"
+
+#ifdef AP_HOST_EMU
+#define AP_STORE2(p, v, NT) (*(p) = (v))
+#else
+#define AP_STORE2(p, v, NT)                                      \
+    do {                                                         \
+        if (NT) __builtin_nontemporal_store((v), (p));           \
+        else *(p) = (v);                                         \
+    } while (0)
+#endif
+
+template <int PADGEN, int ALIGNED, int NT>
+__global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApStft16Params P) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = AP_UNIFORM(tid >> 6);
+    ap_float2 *X = reinterpret_cast<ap_float2 *>(ap_smem) + wave * APW_X_COMPLEX;
+    const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
+    const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
+    const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);
+    ap_float2 *OB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);        // [2][129][17]
+    apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid,
+                    64 * APS_WAVES);
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    AP_LDS_BARRIER();
+
+#ifndef AP_HOST_EMU
+    // Every workgroup alternates a compute phase (two transforms) with a burst of 131 KB of stores, all 256 of
+    // them with the same period: started together they also burst together, the memory system idles during the
+    // transforms and the stores queue up behind each other during the bursts.  A start-up delay of a quarter
+    // period per workgroup class spreads the bursts over the period.
+    for (int d = (int)((blockIdx.x >> 3) & 3) * P.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
+#endif
+    const int F = APW_NC + 1;
+    const int sq0 = tid >> 4, sf0 = tid & 15;                                // store role of this thread
+    const int Ts = (int)P.Ts, Ts15 = (int)(P.Ts & 15);
+    ap_float2 carry[8][4], carry_mid = ap_mk(0.0f, 0.0f);
+    if (!ALIGNED) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) carry[c][i] = ap_mk(0.0f, 0.0f);
+    }
+    ap_float2 raw[16];
+    // frame t0 + wave + 8 * second of the group
+    auto load_frame = [&](int64_t group, int second) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t = (group - b * P.groups_per_clip) * APS16_G + wave + 8 * second;
+        const float *yb = P.y + b * P.L;
+        const ApClip clip = ap_clip_make(yb, P.L);
+        const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
+        // frames beyond T read past the clip: zeros (never stored).  Edge / reflect padding only
+        // touches the frames that overlap a clip boundary.
+        const bool inside = !PADGEN || t >= P.T || (base >= 0 && base + 2 * APW_NC <= P.L);
+        if (inside) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
+                raw[j] = ap_clip_load2(clip, (int)p);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int64_t p = base + 2 * (lane + 64 * j);
+                raw[j] = ap_mk(ap_load_padded(yb, P.L, p, P.pad_mode), ap_load_padded(yb, P.L, p + 1, P.pad_mode));
+            }
+        }
+    };
+    // windowed frame in raw[] -> xk[r] = X[lane + 64 r], xm[r] = X[1024 - lane - 64 r], zh = Z[512]
+    auto transform = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 &zh, int64_t next_group, int next_second) {
+        ap_float2 v[16];
+        AP_SCHED_FENCE();
+        // window in four batches: the 16 table values never sit in registers together (this is where the
+        // first frame's spectrum, the prefetched samples and the carries meet)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ap_float2 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = WIN[lane + 64 * (4 * q + j)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * q + j] = ap_mul2(raw[4 * q + j], w[j]);
+            AP_SCHED_FENCE();
+        }
+        if (!PADGEN && next_group >= 0) load_frame(next_group, next_second);   // lands under the transform
+        AP_SCHED_FENCE();
+        apw_forward<true, !ALIGNED>(v, X, TW1, lc);
+        AP_SCHED_FENCE();
+        ApwLane ls = lc;
+        if (!ALIGNED) {                      // keeps the 8 split twiddles from being hoisted out of the group loop
+            AP_PIN(ls.tws0h.x);
+            AP_PIN(ls.tws0h.y);
+        }
+        apw_split<true>(X, ls, xk, xm, zh);
+        AP_SCHED_FENCE();
+    };
+
+    // every workgroup owns a contiguous stretch of the (clip, 16-frame group) stream: a row's
+    // window is completed one group later by the same thread (ALIGNED = 0), and the lines of
+    // consecutive groups follow each other from the same CU
+    const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (!PADGEN && g_lo < g_hi) load_frame(g_lo, 0);
+
+    for (int64_t group = g_lo; group < g_hi; ++group) {
+        const int64_t b = group / P.groups_per_clip;
+        const int64_t t0 = (group - b * P.groups_per_clip) * APS16_G;
+        ap_float2 *ob = P.out + b * (int64_t)F * P.Ts + t0;
+        // (complex index of out[b, 0, t0]) mod 16: the same for every group of a clip
+        const int a0 = (int)(((reinterpret_cast<uintptr_t>(P.out) >> 3) + (uint64_t)(b * (int64_t)F * P.Ts + t0)) & 15);
+        const bool have_prev = group > g_lo && t0 > 0;          // carries hold this clip's previous group
+        const bool last = group + 1 == g_hi || t0 + APS16_G >= P.T;
+        const int trem = (int)(P.T - t0);                        // frames t0 + i with i < trem exist
+
+        ap_float2 xkA[8], xmA[8], zhA, xkB[8], xmB[8], zhB;
+        if (PADGEN) load_frame(group, 0);
+        transform(xkA, xmA, zhA, group, 1);
+        if (PADGEN) load_frame(group, 1);
+        transform(xkB, xmB, zhB, -1, 0);
+        // the next group's first frame lands under the store phase (during the second transform the
+        // registers hold the first frame's spectrum instead)
+        AP_SCHED_FENCE();
+        if (!PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
+        AP_SCHED_FENCE();
+
+        // ---- transposed store: chunk c holds bins 64 c + lane and 1024 - 64 c - lane ----------
+        // (the thread's store role is made opaque per group: otherwise the compiler hoists the row
+        //  offsets of all 33 elements out of the group loop and spills the carries to make room)
+        int sq = sq0, sf = sf0;
+        AP_PIN(sq);
+        AP_PIN(sf);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ap_float2 *buf = OB + (c & 1) * (APS16_OB_ROWS * APS16_OB_ROW);
+            buf[lane * APS16_OB_ROW + wave] = xkA[c];
+            buf[lane * APS16_OB_ROW + 8 + wave] = xkB[c];
+            buf[(64 + lane) * APS16_OB_ROW + wave] = xmA[c];
+            buf[(64 + lane) * APS16_OB_ROW + 8 + wave] = xmB[c];
+            if (c == 7 && lane == 0) {                             // X[512] = conj Z[512]
+                buf[128 * APS16_OB_ROW + wave] = ap_mk(zhA.x, -zhA.y);
+                buf[128 * APS16_OB_ROW + 8 + wave] = ap_mk(zhB.x, -zhB.y);
+            }
+            AP_LDS_BARRIER();
+            // thread (sq = tid / 16, sf = tid % 16) owns position sf of the windows of the chunk's rows
+            // sq, 32 + sq (bins 64 c + l) and 64 + sq, 96 + sq (bins 1024 - 64 c - l), l = sq, 32 + sq
+            int bins[5], slots[5];
+            const int ne = c == 7 ? 5 : 4;                         // + bin 512 in the last chunk
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int l = sq + 32 * (i & 1);
+                bins[i] = (i >> 1) ? APW_NC - 64 * c - l : 64 * c + l;
+                slots[i] = (i >> 1) * 64 + l;
+            }
+            bins[4] = APW_NC / 2;
+            slots[4] = 128;
+            if (ALIGNED) {
+                ap_float2 x[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    if (i < ne) x[i] = buf[slots[i] * APS16_OB_ROW + sf];
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    if (i < ne) {
+                        const bool mine = i < 4 || tid < APS16_G;
+                        if (mine && sf < trem) AP_STORE2(&ob[bins[i] * Ts + sf], x[i], NT);
+                    }
+            } else {
+                // One LDS read per element: frame (sf + phi) mod 16 of this group is either stored now
+                // (sf >= 16 - phi) or becomes the carry while the old carry is stored.
+                int phi[5];
+                ap_float2 x[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    if (i < ne) {                                  // all LDS reads of the chunk first
+                        phi[i] = (0 - (a0 + bins[i] * Ts15)) & 15;
+                        x[i] = buf[slots[i] * APS16_OB_ROW + ((sf + phi[i]) & 15)];
+                    }
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    if (i < ne) {
+                        ap_float2 &cy = i < 4 ? carry[c][i] : carry_mid;
+                        const bool mine = i < 4 || tid < APS16_G;
+                        const bool take = sf < 16 - phi[i];
+                        const int dt = phi[i] + sf - 16;           // frame t0 + dt of the row
+                        const ap_float2 val = take ? cy : x[i];
+                        if (mine && (take ? have_prev : dt < trem)) AP_STORE2(&ob[bins[i] * Ts + dt], val, NT);
+                        if (take) cy = x[i];
+                    }
+                if (last) {                                        // flush: the carries just taken
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if (i < ne) {
+                            const bool mine = i < 4 || tid < APS16_G;
+                            if (mine && sf < 16 - phi[i] && phi[i] + sf < trem)
+                                AP_STORE2(&ob[bins[i] * Ts + phi[i] + sf], x[i], NT);
+                        }
+                }
+            }
+        }
+    }
+}

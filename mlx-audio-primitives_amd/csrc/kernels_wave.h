@@ -284,10 +284,55 @@ AP_DEV void apm_quad_radix4(ap_float2 (&v)[16], const ApmLane &m) {
 // windowed samples v[j] = z[lane + 64 j]  ->  Z[k] in natural order in the wave's X buffer
 // (slots apw_zidx(k)).  16 x 16 x 4: two in-register radix-16 passes around LDS transpose #1,
 // the radix-4 across the quad with DPP, then LDS transpose #2.
-template <bool TO_LDS = true>
+// The radix-16 butterfly with a scheduling fence after each of its eight radix-4 groups: hipcc's
+// scheduler otherwise interleaves all of them (about 80 live temporaries at 2 waves per SIMD), which
+// kernels that keep other state in registers across the transform (kernels_stft16.h) cannot afford.
+AP_DEV void apw_butterfly16_tight(ap_float2 (&v)[16]) {
+    ap_float2 a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a[r][0] = v[r]; a[r][1] = v[r + 4]; a[r][2] = v[r + 8]; a[r][3] = v[r + 12];
+        ap_fft4(a[r][0], a[r][1], a[r][2], a[r][3]);
+        AP_SCHED_FENCE();
+    }
+    const float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f;
+    const float H = 0.70710678118654752440f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {            // twiddles W16^(r p) as in ApButterfly<16>::finish, column by column
+        if (p == 1) {
+            a[1][1] = ap_mul_fw_c(a[1][1], C1, S1);
+            a[2][1] = ap_mul_fw_c(a[2][1], H, H);
+            a[3][1] = ap_mul_fw_c(a[3][1], S1, C1);
+        } else if (p == 2) {
+            a[1][2] = ap_mul_fw_c(a[1][2], H, H);
+            a[3][2] = ap_mul_fw_c(a[3][2], -H, H);
+        } else if (p == 3) {
+            a[1][3] = ap_mul_fw_c(a[1][3], S1, C1);
+            a[2][3] = ap_mul_fw_c(a[2][3], -H, H);
+            a[3][3] = ap_mul_fw_c(a[3][3], -C1, -S1);
+        }
+        if (p == 2) ap_fft4_a2mi(a[0][p], a[1][p], a[2][p], a[3][p]);
+        else ap_fft4(a[0][p], a[1][p], a[2][p], a[3][p]);
+        v[p] = a[0][p]; v[p + 4] = a[1][p]; v[p + 8] = a[2][p]; v[p + 12] = a[3][p];
+        AP_SCHED_FENCE();
+    }
+}
+
+template <bool TO_LDS = true, bool TIGHT = false>
 AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ApwLane &c) {
     const int lane = c.lane;
-    {
+    if (TIGHT) {                                                   // twiddles fetched after the butterfly
+        apw_butterfly16_tight(v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ap_float2 t1[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (8 * h + k) t1[k] = TW1[(8 * h + k) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (8 * h + k) v[8 * h + k] = ap_mul_fw(v[8 * h + k], t1[k]);
+            AP_SCHED_FENCE();
+        }
+    } else {
         ap_float2 t1[16];
 #pragma unroll
         for (int k = 1; k < 16; ++k) t1[k] = TW1[k * 64 + lane];   // lands during the butterfly
@@ -304,14 +349,30 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
     ap_float2 t2[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = X[APW_T1(lane) + i];
+    if (!TIGHT) {
 #pragma unroll
-    for (int cc = 1; cc < 16; ++cc) t2[cc] = c.tw2row[cc];         // W_64^(a*c)
+        for (int cc = 1; cc < 16; ++cc) t2[cc] = c.tw2row[cc];     // W_64^(a*c)
+    }
     AP_WAVE_SYNC();
-    ApButterfly<16>::run(v);
     const ApmLane m = apm_lane_init(lane);
-    v[0] = ap_scale(v[0], m.sg);
+    if (TIGHT) {
+        AP_SCHED_FENCE();
+        apw_butterfly16_tight(v);
+        v[0] = ap_scale(v[0], m.sg);
 #pragma unroll
-    for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);      // the table carries the signs s1 s2
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (8 * h + k) t2[k] = c.tw2row[8 * h + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (8 * h + k) v[8 * h + k] = ap_mul_fw(v[8 * h + k], t2[k]);
+            AP_SCHED_FENCE();
+        }
+    } else {
+        ApButterfly<16>::run(v);
+        v[0] = ap_scale(v[0], m.sg);
+#pragma unroll
+        for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);  // the table carries the signs s1 s2
+    }
     // radix-4 across the quad (DIF) on v_fmac_f32_dpp, outputs in bit-reversed lanes
     apm_quad_radix4(v, m);
     // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d (skipped when the caller stores

@@ -1,0 +1,39 @@
+// Translation unit of the 16-frames-per-group STFT kernel (kernels_stft16.h).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+
+#define AP_TU_SECONDARY 1
+#include "ap_tu.h"
+#include "kernels_stft16.h"
+
+template <int PADGEN, int ALIGNED, int NT>
+static int ap_stft16_go(const ApStft16Params &W, int grid, void *stream) {
+    auto kern = ap_stft2048_g16_kernel<PADGEN, ALIGNED, NT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, W.lds_bytes);
+    if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipFuncSetAttribute(LDS=%d): %s", W.lds_bytes, hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+    e = hipGetLastError();
+    if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "ap_stft_f32(g16): %s", hipGetErrorString(e));
+    return AP_OK;
+}
+
+int ap_launch_stft16(const ApStftParams &P, int64_t B, int64_t Ts, void *stream) {
+    ApStft16Params W;
+    int grid = 0, aligned = 0;
+    if (ap_prepare_stft16(W, P, B, Ts, &grid, &aligned) != AP_OK) return 1;
+    // A/B switches for measurements: AP_STFT16_NT=1 non-temporal stores, AP_STFT16_CARRY=1 keeps the carry path
+    // on an aligned layout
+    static const bool nt = std::getenv("AP_STFT16_NT") && std::atoi(std::getenv("AP_STFT16_NT")) != 0;
+    static const bool force_carry = std::getenv("AP_STFT16_CARRY") != nullptr;
+    if (force_carry) aligned = 0;
+    static const int stagger = std::getenv("AP_STFT16_STAGGER") ? std::atoi(std::getenv("AP_STFT16_STAGGER")) : 0;
+    W.stagger = stagger;
+    const bool pg = !ap_clip_loads_ok(W);
+    if (aligned) {
+        if (pg) return nt ? ap_stft16_go<1, 1, 1>(W, grid, stream) : ap_stft16_go<1, 1, 0>(W, grid, stream);
+        return nt ? ap_stft16_go<0, 1, 1>(W, grid, stream) : ap_stft16_go<0, 1, 0>(W, grid, stream);
+    }
+    if (pg) return nt ? ap_stft16_go<1, 0, 1>(W, grid, stream) : ap_stft16_go<1, 0, 0>(W, grid, stream);
+    return nt ? ap_stft16_go<0, 0, 1>(W, grid, stream) : ap_stft16_go<0, 0, 0>(W, grid, stream);
+}

@@ -144,6 +144,47 @@ def stft(y, n_fft: int = 2048, hop_length: int | None = None, win_length: int | 
     return S[0] if one_d else S
 
 
+def _padded_row_stride(S: torch.Tensor):
+    """Row stride (complex values) of a (B, F, T) view whose rows are padded but otherwise dense, else None."""
+    if S.ndim != 3 or S.is_contiguous():
+        return None
+    B, F, T = S.shape
+    sb, sf, st = S.stride()
+    if T > 0 and st == 1 and sf > T and (B == 1 or sb == F * sf):
+        return int(sf)
+    return None
+
+
+def stft_padded_rows(y, n_fft: int = 2048, hop_length: int | None = None, win_length: int | None = None,
+                     window="hann", center: bool = True, pad_mode: str = "constant",
+                     row_multiple: int = 16, out: torch.Tensor | None = None) -> torch.Tensor:
+    """`stft` into a buffer whose rows are padded to a multiple of `row_multiple` frames (n_fft = 2048).
+
+    Returns the (batch, n_fft//2+1, n_frames) result as a strided VIEW of the padded buffer: same
+    values as `stft`, but every row starts on a 128-byte line, so the kernel writes whole lines and
+    needs no carries (ap_stft_rows_f32; the layout the Griffin-Lim workspaces use).  Not part of the
+    reference's API: its `stft` always returns the dense array (stft.py:216)."""
+    hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
+    y = _x.to_device_f32(y)
+    if y.ndim != 2:
+        raise ValueError(f"y must be 2D, got {y.ndim}D")
+    B, L = y.shape
+    dev = y.device
+    win = _get_padded_window(window, win_length, n_fft, dev)
+    T = _frame_count(L, n_fft, hop_length, center, pad_mode)
+    F = n_fft // 2 + 1
+    Ts = -(-T // row_multiple) * row_multiple
+    if out is None:                        # the padding columns are never written (nor read by this package)
+        out = torch.empty((B, F, Ts, 2), dtype=torch.float32, device=dev)
+    elif out.shape != (B, F, Ts, 2) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"out must be a contiguous float32 tensor of shape {(B, F, Ts, 2)} on {dev}")
+    tw = _get_twiddles(n_fft, dev)
+    _x.check(_x.dlib(dev).ap_stft_rows_f32(_x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win),
+                                           _x.ptr(tw), int(bool(center)), _x.PAD_MODES[pad_mode], T, Ts,
+                                           _x.ptr(out), _x.stream_ptr(dev)))
+    return torch.view_as_complex(out)[:, :, :T]
+
+
 def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = None,
           n_fft: int | None = None, window="hann", center: bool = True,
           length: int | None = None) -> torch.Tensor:
@@ -158,8 +199,14 @@ def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = N
         stft_matrix = stft_matrix[None, :]
     dev = stft_matrix.device if stft_matrix.is_cuda else _x.require_device()
     _x.lib()
-    S = stft_matrix.to(device=dev, dtype=torch.complex64).contiguous()
+    S = stft_matrix.to(device=dev, dtype=torch.complex64)
     B, F, T = S.shape
+    # rows padded to whole 128-byte lines (stft_padded_rows / ap_stft_rows_f32) are read in place by the
+    # fused n_fft = 2048 kernel; every other strided view is made dense first
+    row_stride = _padded_row_stride(S)
+    if row_stride is None or F != 1025 or (n_fft is not None and n_fft != 2048):
+        S = S.contiguous()
+        row_stride = None
     if n_fft is None:
         n_fft = 2 * (F - 1)
     if hop_length is None:
@@ -197,9 +244,19 @@ def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = N
             tgt = y
         else:
             tgt = torch.empty((B, ola_len), dtype=torch.float32, device=dev)
-        _x.check(_x.dlib(dev).ap_istft_f32(_x.ptr(Sr), B, T, int(n_fft), int(hop_length), _x.ptr(win),
-                                       _x.ptr(tw), _x.ptr(ws), offset, ola_len, _x.ptr(tgt),
-                                       _x.stream_ptr(dev)))
+        rc = _x.AP_ERR_UNSUPPORTED if row_stride is not None else None
+        if row_stride is not None:
+            rc = _x.dlib(dev).ap_istft_rows_f32(_x.ptr(Sr), B, T, row_stride, int(n_fft), int(hop_length),
+                                                _x.ptr(win), _x.ptr(tw), offset, ola_len, _x.ptr(tgt),
+                                                _x.stream_ptr(dev))
+            if rc == _x.AP_ERR_UNSUPPORTED:                  # hop the fused kernel does not serve: dense copy
+                S = S.contiguous()
+                Sr = torch.view_as_real(S)
+        if rc is None or rc == _x.AP_ERR_UNSUPPORTED:
+            rc = _x.dlib(dev).ap_istft_f32(_x.ptr(Sr), B, T, int(n_fft), int(hop_length), _x.ptr(win),
+                                           _x.ptr(tw), _x.ptr(ws), offset, ola_len, _x.ptr(tgt),
+                                           _x.stream_ptr(dev))
+        _x.check(rc)
         if tgt is not y:
             y[:, :ola_len] = tgt
     return y[0] if two_d else y

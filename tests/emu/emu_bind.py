@@ -82,6 +82,28 @@ def stft(y, n_fft, hop, window, center=True, pad_mode=0):
     return out[..., 0] + 1j * out[..., 1]
 
 
+def stft16(y, hop, window, center=True, pad_mode=0, Ts=None, grid_cap=2, misalign=0, force_unaligned=False):
+    """kernels_stft16.h: (B, 1025, T) complex with rows Ts apart, written at an offset of `misalign`
+    complex values from a 128-byte aligned base.  Returns (spectrum, whole buffer, aligned flag)."""
+    y = np.ascontiguousarray(y, np.float32)
+    B, L = y.shape
+    T = n_frames(L, 2048, hop, center)
+    Ts = T if Ts is None else Ts
+    n = B * 1025 * Ts
+    raw = np.full(2 * (n + 64) + 32, np.float32(-777.0), np.float32)
+    off = (-raw.ctypes.data // 4) % 32 + 2 * misalign          # floats to a 128-byte boundary
+    out = raw[off:off + 2 * n]
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(2048)
+    rc = lib().emu_stft16_f32(_p(y), _i64(B), _i64(L), hop, _p(window), _p(tw), int(center), pad_mode,
+                              _i64(T), _i64(Ts), _p(out), grid_cap, int(force_unaligned))
+    if rc < 0:
+        _check(rc)
+    full = out.reshape(B, 1025, Ts, 2)
+    S = full[:, :, :T, 0] + 1j * full[:, :, :T, 1]
+    return S, raw, off, rc
+
+
 def mel_plan(fb):
     fb = np.ascontiguousarray(fb, np.float32)
     M, F = fb.shape
@@ -268,6 +290,23 @@ def istft_fused(S, hop, window, out_len, out_offset=None, grid_cap=0):
     fn = lib().emu_istft_fused_f32 if n_fft == 2048 else lib().emu_istft1024_fused_f32
     _check(fn(_p(Sv), _i64(B), _i64(T), hop, _p(window), _p(tw), _i64(out_offset), _i64(out_len), grid_cap,
               _p(out)))
+    return out
+
+
+def istft16(S, hop, window, out_len, out_offset=1024, grid_cap=0, Ts=None):
+    """kernels_istft16.h: fused ISTFT of an n_fft = 2048 (B, 1025, T) spectrum held with rows Ts apart."""
+    S = np.ascontiguousarray(S, np.complex64)
+    B, F, T = S.shape
+    assert F == 1025
+    Ts = T if Ts is None else Ts
+    buf = np.full((B, F, Ts), np.complex64(7e3 + 9e3j), np.complex64)     # padding the kernel must not use
+    buf[:, :, :T] = S
+    Sv = np.ascontiguousarray(buf.view(np.float32))
+    out = np.full((B, out_len), np.float32(-555.0), np.float32)
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(2048)
+    _check(lib().emu_istft16_f32(_p(Sv), _i64(B), _i64(T), _i64(Ts), hop, _p(window), _p(tw), _i64(out_offset),
+                                 _i64(out_len), grid_cap, _p(out)))
     return out
 
 

@@ -15,6 +15,8 @@ alignas(16) char ap_smem[160 * 1024];
 #include "../../mlx-audio-primitives_amd/csrc/kernels_wave512.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_mel2048.h"
 #include "../../mlx-audio-primitives_amd/csrc/kernels_frames8.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_stft16.h"
+#include "../../mlx-audio-primitives_amd/csrc/kernels_istft16.h"
 
 static thread_local char g_err[512] = "";
 char *ap_error_buffer() { return g_err; }
@@ -160,6 +162,30 @@ int emu_stft_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const
         return AP_OK;
     emu_lds_limit(P.tile.lds_bytes), emu_launch((unsigned)(P.tiles_per_clip * B), AP_BLOCK, [&] { ap_stft_generic_kernel<0>(P); });
     return AP_OK;
+}
+
+// n_fft = 2048 STFT on the 16-frames-per-group kernel (kernels_stft16.h); `out` has rows Ts complex apart
+int emu_stft16_f32(const float *y, int64_t B, int64_t L, int hop, const float *window, const float *tw,
+                   int center, int pad_mode, int64_t T, int64_t Ts, float *out, int grid_cap, int force_unaligned) {
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, 2048, hop, window, tw, center, pad_mode, T);
+    if (rc != AP_OK) return rc;
+    P.out_c = reinterpret_cast<ap_float2 *>(out);
+    ApStft16Params W;
+    int grid = 0, aligned = 0;
+    if (ap_prepare_stft16(W, P, B, Ts, &grid, &aligned) != AP_OK) return AP_ERR_UNSUPPORTED;
+    if (force_unaligned) aligned = 0;
+    if (grid > grid_cap) grid = grid_cap;   // exercise the persistent group loop and the carries
+    const bool pg = !ap_clip_loads_ok(W);
+    emu_lds_limit(W.lds_bytes);
+    if (aligned) {
+        if (pg) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<1, 1, 0>(W); });
+        else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<0, 1, 0>(W); });
+    } else {
+        if (pg) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<1, 0, 0>(W); });
+        else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<0, 0, 0>(W); });
+    }
+    return aligned;
 }
 
 int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
@@ -397,6 +423,18 @@ int emu_istft_fused_f32(const float *S, int64_t B, int64_t T, int hop, const flo
     }
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
     emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_irfft2048_wave_kernel<1>(W); });
+    return AP_OK;
+}
+
+// n_fft = 2048 fused ISTFT with 16-frame loads (kernels_istft16.h); S has rows Ts complex apart
+int emu_istft16_f32(const float *S, int64_t B, int64_t T, int64_t Ts, int hop, const float *window, const float *tw,
+                    int64_t out_offset, int64_t out_len, int grid_cap, float *out) {
+    ApIstft16Params W;
+    int grid = 0;
+    if (ap_prepare_istft16(W, S, tw, B, T, Ts, window, hop, out_offset, out_len, out, &grid) != AP_OK)
+        return AP_ERR_UNSUPPORTED;
+    if (grid_cap > 0) grid = grid_cap < (int)W.n_g16 ? grid_cap : (int)W.n_g16;
+    emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel(W); });
     return AP_OK;
 }
 

@@ -52,6 +52,41 @@ def test_emu_stft(n_fft, hop, L, B, pad_mode, center):
     np.testing.assert_allclose(S, R, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("hop,L,B,pad_mode,center,Ts,grid_cap,misalign,force_unaligned", [
+    # contiguous rows (Ts = T): line-aligned windows with register carries; 3 clips x 22 frames = 6 groups
+    # on 2 workgroups (a clip change inside a stretch, a stretch that ends mid-clip), T odd and even
+    (512, 10752, 3, "constant", True, None, 2, 0, False),
+    (512, 20000, 2, "constant", True, None, 1, 3, False),      # 40 frames: 3 groups per clip, one workgroup
+    (512, 20000, 2, "constant", True, None, 5, 0, False),      # more workgroups than clips: stretches start mid-clip
+    (512, 9300, 2, "constant", False, None, 2, 5, False),
+    (512, 6000, 1, "reflect", True, None, 2, 0, False),
+    (300, 9000, 2, "constant", True, None, 2, 1, False),
+    (255, 5000, 1, "constant", True, None, 2, 0, False),       # centred frames at an odd hop: index-remapped loads
+    # padded rows (Ts a multiple of 16, aligned base): whole lines, no carries
+    (512, 10752, 3, "constant", True, 32, 2, 0, False),
+    (512, 20000, 2, "edge", True, 48, 3, 0, False),
+    # ... and the carry path on the same layout (phi = 0 everywhere: every store lags a whole group)
+    (512, 20000, 2, "constant", True, 48, 3, 0, True),
+    (512, 20000, 1, "constant", True, 45, 2, 7, False),        # padded, but not to a line
+])
+def test_emu_stft16(hop, L, B, pad_mode, center, Ts, grid_cap, misalign, force_unaligned):
+    """kernels_stft16.h (n_fft = 2048, 16 frames per group, 128-byte row windows) on the CPU."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 2048, 2048)
+    S, raw, off, aligned = eb.stft16(y, hop, win, center, PM[pad_mode], Ts, grid_cap, misalign, force_unaligned)
+    R = ao.stft(y, n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode)
+    assert S.shape == R.shape
+    np.testing.assert_allclose(S, R, rtol=1e-4, atol=1e-4)
+    T = R.shape[-1]
+    Tr = T if Ts is None else Ts
+    assert aligned == int(Tr % 16 == 0 and misalign == 0 and not force_unaligned)
+    # nothing outside the T frames of every row was touched (row padding, guard floats either side)
+    n = B * 1025 * Tr
+    assert np.all(raw[:off] == -777.0) and np.all(raw[off + 2 * n:] == -777.0)
+    assert np.all(raw[off:off + 2 * n].reshape(B, 1025, Tr, 2)[:, :, T:] == -777.0)
+
+
 @pytest.mark.parametrize("sr,n_fft,hop,M,L,B,power", [
     (22050, 2048, 512, 128, 9000, 2, 2.0),
     (16000, 400, 160, 80, 5000, 3, 2.0),
@@ -191,6 +226,40 @@ def test_emu_istft_fused(hop, L, B, grid_cap):
     for length in (L, L - 700):
         out = eb.istft_fused(S, hop, win, length, grid_cap=grid_cap)
         np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=2048, length=length), atol=1e-5)
+
+
+@pytest.mark.parametrize("hop,L,B,grid_cap,Ts", [
+    (512, 10752, 3, 2, None),       # T = 22: two 16-frame groups per clip, the second with 6 frames; clip change in a stretch
+    (512, 20000, 2, 5, None),       # T = 40: stretches that start inside a clip (8-frame warm-up step)
+    (512, 20000, 2, 3, 48),         # padded rows (whole 128-byte lines)
+    (512, 11300, 2, 1, None),       # T = 23: second step with 7 frames
+    (512, 12400, 2, 4, 30),         # T = 25: the clip ends after a first step (one frame in the last group)
+    (1024, 30000, 2, 2, None),
+    (256, 9000, 1, 2, None),
+    (512, 6000, 1, 0, None),
+])
+def test_emu_istft16(hop, L, B, grid_cap, Ts):
+    """kernels_istft16.h: 16-frame loads as they fall, two 8-frame overlap-add steps per load."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ao.stft(y, n_fft=2048, hop_length=hop)
+    win = ao.padded_window("hann", 2048, 2048)
+    for length in (L, L - 700):
+        out = eb.istft16(S, hop, win, length, grid_cap=grid_cap, Ts=Ts)
+        np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=2048, length=length), atol=1e-5)
+    # center=False: no trim, output longer than the frames reach (zero tail)
+    # (where the window sum of squares is tiny - the first and last samples of a clip without centring - float32
+    #  rounding of the frames is amplified by up to 1e8: compare where the divisor is not)
+    n = L + 2048 + 100
+    out = eb.istft16(S, hop, win, n, out_offset=0, grid_cap=grid_cap, Ts=Ts)
+    ref = ao.istft(S, hop_length=hop, n_fft=2048, center=False, length=n)
+    wss = np.zeros(n + 2048)
+    for t in range(S.shape[-1]):
+        wss[t * hop:t * hop + 2048] += win.astype(np.float64) ** 2
+    ok = wss[:n] > 1e-2
+    np.testing.assert_allclose(out[:, ok], ref[:, ok], atol=1e-5)
+    reach = (S.shape[-1] - 1) * hop + 2048
+    assert np.all(out[:, reach:] == 0.0)
 
 
 @pytest.mark.parametrize("hop,L,B,grid_cap", [(256, 5376, 3, 2), (128, 4000, 2, 3), (512, 15000, 2, 2),

