@@ -290,6 +290,10 @@ int ap_resample_fft_chirp_f32(const float *x /*dev (B,Nx)*/, int64_t B, int64_t 
  * stft.py:347-379 (mx.abs, mx.arctan2). */
 int ap_magnitude_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);
 int ap_phase_f32(const float *S /*dev*/, int64_t n, float *out /*dev*/, void *stream);
+/* The same two from a spectrum whose rows are `row_stride` complex values apart (ap_stft_rows_f32) into a dense
+ * (rows, T) float array: mode 0 = |S|, mode 1 = atan2(im, re). */
+int ap_complex_unary_rows_f32(const float *S /*dev (rows,row_stride,2)*/, int64_t rows, int64_t T, int64_t row_stride,
+                              int mode, float *out /*dev (rows,T)*/, void *stream);
 
 /* ---------------------------------------------------------------------- *
  * Tails of the hot path: Griffin-Lim projection, dB conversion, DCT (mfcc).
@@ -322,6 +326,24 @@ int ap_griffinlim_f32(const float *S /*dev (B,F,T)*/, const float *angles /*dev 
                       const float *tw /*dev*/, int center, int pad_mode, int64_t out_offset,
                       int64_t y_len, int64_t TR, int n_iter, float momentum, float *rebuilt,
                       float *tprev, float *R, float *frames_ws, float *y /*dev*/, void *stream);
+
+/* The same loop with the three complex workspaces held in rows `row_stride` complex values apart
+ * ((B, F, row_stride) each; row_stride even, >= T, ideally a multiple of 16 with 128-byte aligned buffers so
+ * that every 16-frame group is one whole line per row).  n_fft = 2048, hop in {256, 512, 1024}, TR == T (the
+ * stft of the y_len-sample signal has as many frames as S) - AP_ERR_UNSUPPORTED otherwise: use
+ * ap_griffinlim_f32.  S and angles are dense (B, F, T).  No frames workspace: the istft is the fused kernel. */
+int ap_griffinlim_rows_f32(const float *S /*dev (B,F,T)*/, const float *angles /*dev (B,F,T)*/, int64_t B,
+                           int64_t T, int64_t row_stride, int n_fft, int hop, const float *window /*dev*/,
+                           const float *tw /*dev*/, int center, int pad_mode, int64_t out_offset,
+                           int64_t y_len, int n_iter, float momentum, float *rebuilt, float *tprev, float *R,
+                           float *y /*dev*/, void *stream);
+
+/* out[0] = mean((a - b)^2) over n floats, deterministic (float64 partial sums per workgroup, added in a fixed
+ * order): the reconstruction error griffinlim_iter returns (griffinlim.py:268-269).  ws: scratch of
+ * ap_mse_workspace_doubles() float64 values. */
+int64_t ap_mse_workspace_doubles(void);
+int ap_mse_f32(const float *a /*dev*/, const float *b /*dev*/, int64_t n, double *ws /*dev*/, float *out /*dev*/,
+               void *stream);
 
 /* max over n floats into *key_dev (uint32 order-preserving key; caller provides the
  * 4-byte word, the call resets it first).  Used for ref=max and by ap_to_db_f32. */

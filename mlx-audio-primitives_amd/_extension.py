@@ -48,12 +48,12 @@ ABI_SYMBOLS = [
     "ap_mel_plan_words", "ap_mel_plan_host",
     "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
     "ap_stft_f32", "ap_stft_rows_f32", "ap_melspec_f32", "ap_melspec_max_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_rows_f32", "ap_istft_workspace_floats",
-    "ap_magnitude_f32", "ap_phase_f32",
+    "ap_magnitude_f32", "ap_phase_f32", "ap_complex_unary_rows_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_extend_f32", "ap_resample_poly_pad_samples", "ap_resample_poly_padded_f32", "ap_resample_fft_chirp_f32",
     "ap_resample_linear_f32", "ap_gl_project_f32", "ap_reduce_max_f32", "ap_to_db_f32",
     "ap_from_db_f32", "ap_dct_f32", "ap_db_dct_f32", "ap_cfft_split_host", "ap_resample_fft_f32",
-    "ap_pcg64_uniform_f32", "ap_griffinlim_f32",
+    "ap_mse_workspace_doubles", "ap_mse_f32", "ap_pcg64_uniform_f32", "ap_griffinlim_f32", "ap_griffinlim_rows_f32",
     "ap_spectral_stats_f32", "ap_spectral_audio_fused", "ap_spectral_audio_f32", "ap_spectral_contrast_f32", "ap_frame_stats_f32", "ap_preemphasis_f32", "ap_deemphasis_f32", "ap_deemphasis_workspace_floats", "ap_deemphasis_ws_f32", "ap_savgol_f32",
     "ap_autocorrelation_nfft", "ap_autocorrelation_f32", "ap_acf_peaks_f32",
     "ap_pcm16_to_f32", "ap_melspec_pcm16_fused", "ap_melspec_pcm16_f32",
@@ -88,6 +88,7 @@ def _declare(lib) -> None:
         "ap_istft_f32": [P, L, L, I, I, P, P, P, L, L, P, P],
         "ap_istft_rows_f32": [P, L, L, L, I, I, P, P, L, L, P, P],
         "ap_magnitude_f32": [P, L, P, P],
+        "ap_complex_unary_rows_f32": [P, L, L, L, I, P, P],
         "ap_resample_poly_ntaps": [I, I],
         "ap_resample_poly_taps_host": [I, I, P, P],
         "ap_resample_poly_f32": [P, L, L, I, I, P, I, I, L, P, P],
@@ -105,6 +106,8 @@ def _declare(lib) -> None:
         "ap_pcg64_uniform_f32": [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                  ctypes.c_double, ctypes.c_double, L, P, P],
         "ap_griffinlim_f32": [P, P, L, L, I, I, P, P, I, I, L, L, L, I, F, P, P, P, P, P, P],
+        "ap_mse_f32": [P, P, L, P, P, P],
+        "ap_griffinlim_rows_f32": [P, P, L, L, L, I, I, P, P, I, I, L, L, I, F, P, P, P, P, P],
         "ap_resample_fft_f32": [P, L, L, L, P, P, P, P, P, P, P],
         "ap_resample_fft_chirp_f32": [P, L, L, L, L, P, P, P, P, L, P, P, P, P, P, P, P],
         "ap_phase_f32": [P, L, P, P],
@@ -136,6 +139,8 @@ def _declare(lib) -> None:
     lib.ap_resample_poly_pad_samples.restype = L
     lib.ap_deemphasis_workspace_floats.argtypes = [L, L]
     lib.ap_deemphasis_workspace_floats.restype = L
+    lib.ap_mse_workspace_doubles.argtypes = []
+    lib.ap_mse_workspace_doubles.restype = L
 
 
 def _load() -> None:

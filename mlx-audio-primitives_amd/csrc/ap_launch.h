@@ -655,6 +655,7 @@ static inline int ap_prepare_stft16(ApStft16Params &W, const ApStftParams &P, in
     if (off > AP_LDS_MAX) return 1;
     if (Ts > (1 << 20)) return 1;                         // 32-bit row offsets (1024 Ts complex) in the store phase
     W.stagger = 0;
+    W.gl_prev = nullptr; W.gl_mag = nullptr; W.gl_rebuilt = nullptr; W.gl_momentum = 0.0f;
     *aligned = (Ts % APS16_G == 0 && (reinterpret_cast<uintptr_t>(P.out_c) & 127) == 0) ? 1 : 0;
     int64_t g = W.n_groups < 256 ? W.n_groups : 256;      // persistent: one workgroup per CU
     *grid = (int)g;
@@ -684,6 +685,7 @@ static inline int ap_prepare_istft16(ApIstft16Params &W, const float *S, const f
     W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
     W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
     W.off_win = off; off += 2048 * (int)sizeof(float);
+    W.off_inv = off; off += hop * (int)sizeof(float);
     W.off_ib = off; off += ap_align16(2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2));
     W.off_carry = off; off += 2 * (2048 - hop) * (int)sizeof(float);
     W.lds_bytes = off;

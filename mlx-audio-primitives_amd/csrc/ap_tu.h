@@ -7,6 +7,9 @@
 // Returns AP_OK, an error status, or 1 when the shape is not served (the caller falls back).
 int ap_launch_stft16(const ApStftParams &P, int64_t B, int64_t Ts, void *stream);
 
+int ap_launch_stft16_gl(const ApStftParams &P, int64_t B, int64_t Ts, const float *prev, const float *mag, float momentum,
+                        float *rebuilt, void *stream);
+
 // istft16.hip: fused n_fft = 2048 ISTFT with 16-frame loads (kernels_istft16.h); S has rows Ts complex apart.
 // Returns AP_OK, an error status, or 1 when the shape is not served.
 int ap_launch_istft16(const float *S, const float *tw, int64_t B, int64_t T, int64_t Ts, const float *window, int hop,

@@ -76,6 +76,12 @@ struct ApStft16Params {
     int hop, pad, pad_mode;
     int off_tw2, off_tw1, off_win, off_ob, lds_bytes;
     int stagger;               // start-up delay of workgroup i: ((i / 8) % 4) * stagger * 64 * 127 cycles (see the kernel)
+    // fused Griffin-Lim projection (GL = 1 instantiation): previous raw spectrum and the output estimate in the
+    // layout of `out` (rows Ts apart), target magnitudes dense (B, 1025, T)
+    const ap_float2 *gl_prev;
+    const float *gl_mag;
+    ap_float2 *gl_rebuilt;
+    float gl_momentum;
 };
 
 // ---- n_fft = 2048 fused ISTFT, 16-frame loads (kernels_istft16.h) ---------------------------
@@ -86,7 +92,7 @@ struct ApIstft16Params {
     float *y;                  // (B, out_len)
     int64_t T, Ts, g16_per_clip, n_g16, out_offset, out_len;
     int hop;                   // 2048 % hop == 0, hop >= 256
-    int off_tw2, off_tw1, off_win, off_ib, off_carry, lds_bytes;
+    int off_tw2, off_tw1, off_win, off_inv, off_ib, off_carry, lds_bytes;   // off_inv: `hop` reciprocal window sums
 };
 
 struct ApIrfftWaveParams {

@@ -678,6 +678,77 @@ int ap_griffinlim_f32(const float *S, const float *angles, int64_t B, int64_t T,
 }
 
 
+// Griffin-Lim with line-padded workspaces (n_fft = 2048, TR == T): every spectrum of the loop lives with its rows
+// `row_stride` complex values apart, so the STFT writes and the ISTFT reads whole 128-byte lines
+// (kernels_stft16.h ALIGNED = 1, kernels_istft16.h) and the projection moves 16 bytes per lane.
+int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64_t T, int64_t row_stride, int n_fft,
+                           int hop, const float *window, const float *tw, int center, int pad_mode, int64_t out_offset,
+                           int64_t y_len, int n_iter, float momentum, float *rebuilt, float *tprev, float *R, float *y,
+                           void *stream) {
+    if (!S || !angles || !rebuilt || !tprev || !R || !y || !window || !tw) AP_FAIL(AP_ERR_INVALID, "griffinlim: NULL buffer");
+    if (n_iter <= 0) AP_FAIL(AP_ERR_INVALID, "n_iter must be positive, got %d", n_iter);
+    if (momentum < 0.0f || momentum >= 1.0f) AP_FAIL(AP_ERR_INVALID, "momentum must be in [0, 1)");
+    if (n_fft != 2048 || row_stride < T || (row_stride & 1) || row_stride > (1 << 20) ||
+        ((reinterpret_cast<uintptr_t>(rebuilt) | reinterpret_cast<uintptr_t>(tprev) | reinterpret_cast<uintptr_t>(R)) & 15))
+        AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: padded rows need n_fft = 2048, an even row_stride >= T and 16-byte aligned workspaces");
+    if (!ap_istft_fused_shape(B, T, 2048, hop, out_offset)) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: shape not served with padded rows");
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, y_len, n_fft, hop, window, tw, center, pad_mode, T);   // also checks TR == T
+    if (rc != AP_OK) return rc;
+    const int64_t rows = B * 1025;
+    const int64_t pairs = rows * (row_stride / 2);
+    const int grid = ap_grid_1d(pairs, AP_BLOCK, kApStreamGrid);
+    auto project = [&](const float *ang, const float *cur, const float *prev, float *tp) {
+        if (pairs < (int64_t(1) << 31))
+            hipLaunchKernelGGL(ap_gl_rows_kernel<int>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, S, ang,
+                               reinterpret_cast<const ap_float2 *>(cur), reinterpret_cast<const ap_float2 *>(prev), rows,
+                               (int)T, (int)row_stride, momentum, reinterpret_cast<ap_float2 *>(tp),
+                               reinterpret_cast<ap_float2 *>(rebuilt));
+        else
+            hipLaunchKernelGGL(ap_gl_rows_kernel<int64_t>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, S, ang,
+                               reinterpret_cast<const ap_float2 *>(cur), reinterpret_cast<const ap_float2 *>(prev), rows,
+                               (int)T, (int)row_stride, momentum, reinterpret_cast<ap_float2 *>(tp),
+                               reinterpret_cast<ap_float2 *>(rebuilt));
+        return ap_check_launch("ap_griffinlim_rows_f32(project)");
+    };
+    rc = project(angles, nullptr, nullptr, tprev);                    // rebuilt = tprev = S exp(i angles)
+    if (rc != AP_OK) return rc;
+    // raw STFT ping-pong: `tprev` starts as the initial estimate and then alternates with `R` as the previous /
+    // current raw spectrum (S unit(initial estimate) = the initial estimate: S >= 0)
+    float *raw[2] = {R, tprev};
+    for (int it = 0; it < n_iter; ++it) {
+        float *cur = raw[it & 1], *prev = raw[(it + 1) & 1];
+        rc = ap_launch_istft16(rebuilt, tw, B, T, row_stride, window, hop, out_offset, y_len, y, stream);
+        if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: istft shape not served with padded rows");
+        if (rc != AP_OK) return rc;
+        P.out_c = reinterpret_cast<ap_float2 *>(cur);
+        // the projection rides in the STFT's store phase (kernels_stft16.h, GL = 1) when the rows are whole lines;
+        // AP_GL_PROJECT_PASS=1 keeps the separate pass for A/B measurements
+        static const bool separate = std::getenv("AP_GL_PROJECT_PASS") != nullptr;
+        rc = separate ? 1 : ap_launch_stft16_gl(P, B, row_stride, prev, S, momentum, rebuilt, stream);
+        if (rc == 1) {
+            rc = ap_launch_stft16(P, B, row_stride, stream);
+            if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: stft shape not served with padded rows");
+            if (rc != AP_OK) return rc;
+            rc = project(nullptr, cur, prev, nullptr);
+        }
+        if (rc != AP_OK) return rc;
+    }
+    rc = ap_launch_istft16(rebuilt, tw, B, T, row_stride, window, hop, out_offset, y_len, y, stream);
+    if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: istft shape not served with padded rows");
+    return rc;
+}
+
+// out[0] = mean((a - b)^2) over n floats; ws = ap_mse_workspace_doubles() float64 values of scratch
+int64_t ap_mse_workspace_doubles(void) { return kApStreamGrid; }
+int ap_mse_f32(const float *a, const float *b, int64_t n, double *ws, float *out, void *stream) {
+    if (n <= 0 || !a || !b || !ws || !out) AP_FAIL(AP_ERR_INVALID, "mse: bad arguments");
+    const int grid = ap_grid_1d(n, AP_BLOCK, kApStreamGrid);
+    hipLaunchKernelGGL(ap_sqdiff_partial_kernel, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, a, b, n, ws);
+    hipLaunchKernelGGL(ap_sum_partials_kernel, dim3(1), dim3(AP_BLOCK), 0, (hipStream_t)stream, ws, grid, 1.0 / (double)n, out);
+    return ap_check_launch("ap_mse_f32");
+}
+
 int ap_reduce_max_f32(const float *x, int64_t n, uint32_t *key_dev, void *stream) {
     if (!x || !key_dev || n <= 0) AP_FAIL(AP_ERR_INVALID, "reduce_max: bad arguments");
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
@@ -871,6 +942,18 @@ int ap_magnitude_f32(const float *S, int64_t n, float *out, void *stream) {
 
 int ap_phase_f32(const float *S, int64_t n, float *out, void *stream) {
     return ap_complex_unary(S, n, 1, out, stream);
+}
+
+// |S| (mode 0) or atan2 (mode 1) of a spectrum with padded rows -> dense (rows, T) floats
+int ap_complex_unary_rows_f32(const float *S, int64_t rows, int64_t T, int64_t row_stride, int mode, float *out,
+                              void *stream) {
+    if (rows < 0 || T < 0 || row_stride < T || (mode != 0 && mode != 1) || T > 2147483647LL || row_stride > 2147483647LL)
+        AP_FAIL(AP_ERR_INVALID, "magnitude / phase: bad shape");
+    if (rows == 0 || T == 0) return AP_OK;
+    if (!S || !out) AP_FAIL(AP_ERR_INVALID, "magnitude / phase: NULL buffer");
+    hipLaunchKernelGGL(ap_complex_unary_rows_kernel, dim3(ap_grid_1d(rows * T, AP_BLOCK, kApStreamGrid)), dim3(AP_BLOCK), 0,
+                       (hipStream_t)stream, reinterpret_cast<const ap_float2 *>(S), rows, (int)T, (int)row_stride, mode, out);
+    return ap_check_launch("ap_complex_unary_rows_f32");
 }
 
 // ---------------------------------------------------------------------- §8(f): features / framing

@@ -6,6 +6,13 @@
 // Stands in for mx.fft.rfft / mx.fft.irfft (reference stft.py:130, :295), which
 // live in the un-vendored mlx dependency.
 #pragma once
+// Non-template kernels of the kernel headers: one translation unit owns them with external linkage; every
+// other unit that includes the header for its device helpers (AP_TU_SECONDARY) gets private copies.
+#ifdef AP_TU_SECONDARY
+#define AP_KERNEL static __global__
+#else
+#define AP_KERNEL __global__
+#endif
 #include "ap_common.h"
 
 #ifndef AP_DEV

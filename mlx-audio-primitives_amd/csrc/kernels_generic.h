@@ -8,13 +8,6 @@
 // (stft.py:216), mx.abs/mx.power/mx.matmul (mel.py:321-350), mx.fft.irfft
 // (stft.py:295) and overlap_add.metal:16-55.
 #pragma once
-// Non-template kernels of this header: one translation unit owns them with external linkage; every
-// other unit that includes the header for its device helpers (AP_TU_SECONDARY) gets private copies.
-#ifdef AP_TU_SECONDARY
-#define AP_KERNEL static __global__
-#else
-#define AP_KERNEL __global__
-#endif
 #include "fft_lds.h"
 
 #ifndef AP_PAD_CONSTANT
@@ -242,6 +235,18 @@ ap_complex_unary_kernel(const ap_float2 *S, int64_t n, int mode, float *out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
         const ap_float2 v = S[e];
+        out[e] = mode == 0 ? sqrtf(v.x * v.x + v.y * v.y) : atan2f(v.y, v.x);
+    }
+}
+
+// the same from a spectrum whose rows are Ts complex values apart (ap_stft_rows_f32) into a DENSE (rows, T) output
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
+ap_complex_unary_rows_kernel(const ap_float2 *S, int64_t rows, int T, int Ts, int mode, float *out) {
+    const int64_t n = rows * T;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int64_t row = e / T;
+        const ap_float2 v = S[row * Ts + (e - row * T)];
         out[e] = mode == 0 ? sqrtf(v.x * v.x + v.y * v.y) : atan2f(v.y, v.x);
     }
 }

@@ -31,6 +31,14 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
         float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
         for (int i = tid; i < 2 * APW_NC; i += 64 * APS_WAVES) win[i] = P.window[i];
+        // 1 / max(sum of w^2 over the n_fft / hop frames that cover a position, 1e-8) by phase: inside a clip
+        // (every covering frame exists) the divisor of overlap_add.metal:44-52 only depends on the position mod hop
+        float *inv = reinterpret_cast<float *>(ap_smem + P.off_inv);
+        for (int p = tid; p < P.hop; p += 64 * APS_WAVES) {
+            float w2 = 0.0f;
+            for (int q = p; q < 2 * APW_NC; q += P.hop) w2 += P.window[q] * P.window[q];   // increasing frame order = decreasing q
+            inv[p] = 1.0f / fmaxf(w2, 1e-8f);
+        }
     }
     const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
     AP_LDS_BARRIER();
@@ -98,6 +106,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     const int hs = H == 256 ? 8 : (H == 512 ? 9 : 10);           // H = 1 << hs
     const ap_float2 *WINP = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // (w[2n], w[2n+1])
     const float *WIN = reinterpret_cast<const float *>(ap_smem + P.off_win);
+    const float *INV = reinterpret_cast<const float *>(ap_smem + P.off_inv);
     const float *XF = reinterpret_cast<const float *>(ap_smem);  // frame f at XF + f * 2 APW_X_COMPLEX
     const int n_own = APS_WAVES * H;                             // positions one 8-frame step completes
 
@@ -183,28 +192,36 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
                 int F_lo = f_cov < -t0i ? -t0i : f_cov;
                 int F_hi = r >> hs;
                 if (F_hi > Ti - 1 - t0i) F_hi = Ti - 1 - t0i;
-                float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, w3 = 0.0f;
-                for (int Fi = F_lo; Fi <= F_hi; ++Fi) {
-                    const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (r - Fi * H));
-                    w0 += w.x * w.x; w1 += w.y * w.y; w2 += w.z * w.z; w3 += w.w * w.w;
+                float w0, w1, w2, w3;                                // reciprocals of the divisors
+                if (F_lo == f_cov && F_hi == (r >> hs)) {            // every covering frame exists: by phase
+                    const ap_float4 iv = *reinterpret_cast<const ap_float4 *>(INV + (r & (H - 1)));
+                    w0 = iv.x; w1 = iv.y; w2 = iv.z; w3 = iv.w;
+                } else {                                             // the clip's first and last n_fft - hop positions
+                    w0 = w1 = w2 = w3 = 0.0f;
+                    for (int Fi = F_lo; Fi <= F_hi; ++Fi) {
+                        const ap_float4 w = *reinterpret_cast<const ap_float4 *>(WIN + (r - Fi * H));
+                        w0 += w.x * w.x; w1 += w.y * w.y; w2 += w.z * w.z; w3 += w.w * w.w;
+                    }
+                    w0 = 1.0f / fmaxf(w0, 1e-8f); w1 = 1.0f / fmaxf(w1, 1e-8f);
+                    w2 = 1.0f / fmaxf(w2, 1e-8f); w3 = 1.0f / fmaxf(w3, 1e-8f);
                 }
                 const int64_t n = n0 + r;
                 if (n >= 0 && n + 3 < P.out_len) {
                     ap_float4 o4;
-                    o4.x = s0 / fmaxf(w0, 1e-8f);
-                    o4.y = s1 / fmaxf(w1, 1e-8f);
-                    o4.z = s2 / fmaxf(w2, 1e-8f);
-                    o4.w = s3 / fmaxf(w3, 1e-8f);
+                    o4.x = s0 * w0;
+                    o4.y = s1 * w1;
+                    o4.z = s2 * w2;
+                    o4.w = s3 * w3;
                     if (((reinterpret_cast<uintptr_t>(yb + n)) & 15) == 0) {
                         *reinterpret_cast<ap_float4 *>(yb + n) = o4;
                     } else {
                         yb[n] = o4.x; yb[n + 1] = o4.y; yb[n + 2] = o4.z; yb[n + 3] = o4.w;
                     }
                 } else {
-                    if (n >= 0 && n < P.out_len) yb[n] = s0 / fmaxf(w0, 1e-8f);
-                    if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 / fmaxf(w1, 1e-8f);
-                    if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 / fmaxf(w2, 1e-8f);
-                    if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 / fmaxf(w3, 1e-8f);
+                    if (n >= 0 && n < P.out_len) yb[n] = s0 * w0;
+                    if (n + 1 >= 0 && n + 1 < P.out_len) yb[n + 1] = s1 * w1;
+                    if (n + 2 >= 0 && n + 2 < P.out_len) yb[n + 2] = s2 * w2;
+                    if (n + 3 >= 0 && n + 3 < P.out_len) yb[n + 3] = s3 * w3;
                 }
             }
         }

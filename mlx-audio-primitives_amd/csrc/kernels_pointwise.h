@@ -8,7 +8,7 @@
 // mode 0: out = S * exp(i * angles)                        (griffinlim.py:123, init)
 // mode 1: R' = S * exp(i * atan2(R.im, R.re));  rebuilt = R' + m (R' - tprev); tprev = R'
 //         R is (B,F,TR); frames t >= TR are treated as zero (griffinlim.py:156-165 crop/pad)
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_gl_project_kernel(int mode, const float *S, const float *angles, const ap_float2 *R, int64_t TR,
                      int64_t BF, int64_t T, float momentum, ap_float2 *tprev, ap_float2 *rebuilt) {
     const int64_t total = BF * T;
@@ -42,14 +42,28 @@ ap_gl_project_kernel(int mode, const float *S, const float *angles, const ap_flo
 // STFT, so the loop keeps two raw buffers (ping-pong) and this pass reads R_cur, R_prev and S and
 // writes only `rebuilt` (28 instead of 36 bytes per element).  exp(i angle(R)) = R / |R| (1 for
 // R = 0, like atan2(0, 0) = 0).  Needs TR == T.
+// 1 / |r| on the hardware's reciprocal square root (v_rsq_f32, 1 ulp), branch-free; tiny values are scaled up first
+// (|r|^2 would be subnormal below ~1e-19).  The fused Griffin-Lim kernels (kernels_stft16.h) use the same function,
+// so both routes give the same bits.
+AP_DEV float ap_rnorm(ap_float2 &r) {
+    float n2 = r.x * r.x + r.y * r.y;
+    const bool tiny = n2 < 1.0e-30f;
+    r.x = tiny ? r.x * 1.8446744e19f : r.x;            // 2^64
+    r.y = tiny ? r.y * 1.8446744e19f : r.y;
+    n2 = tiny ? r.x * r.x + r.y * r.y : n2;
+#ifdef AP_HOST_EMU
+    return 1.0f / sqrtf(n2);
+#else
+    return __builtin_amdgcn_rsqf(n2);
+#endif
+}
 AP_DEV ap_float2 ap_unit_phase(ap_float2 r) {
-    const float n2 = r.x * r.x + r.y * r.y;
-    if (!(n2 > 0.0f)) return ap_mk(1.0f, 0.0f);
-    const float inv = 1.0f / sqrtf(n2);
-    return ap_mk(r.x * inv, r.y * inv);
+    const float inv = ap_rnorm(r);
+    const bool zero = !(r.x != 0.0f || r.y != 0.0f);    // exp(i atan2(0, 0)) = 1 (NaN inputs propagate)
+    return ap_mk(zero ? 1.0f : r.x * inv, zero ? 0.0f : r.y * inv);
 }
 
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_gl_project2_kernel(const float *S, const ap_float2 *Rcur, const ap_float2 *Rprev, int64_t total,
                       float momentum, ap_float2 *rebuilt) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -67,8 +81,89 @@ ap_gl_project2_kernel(const float *S, const ap_float2 *Rcur, const ap_float2 *Rp
     }
 }
 
+// The same two passes on workspaces whose rows are Ts complex values apart (Ts even, 16-byte aligned rows:
+// the line-padded layout of ap_stft_rows_f32 / ap_istft_rows_f32); S and `angles` stay dense (rows of T).
+// One thread per PAIR of frames: 16-byte accesses on the workspaces.  The padding columns are never touched.
+//   angles != NULL : rebuilt = tprev = S exp(i angles)                       (griffinlim.py:123, init)
+//   angles == NULL : rebuilt = R' + m (R' - S unit(Rprev)),  R' = S unit(Rcur)   (griffinlim.py:168-178)
+template <class IDX>
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_gl_rows_kernel(const float *S, const float *angles, const ap_float2 *Rcur, const ap_float2 *Rprev, int64_t rows,
+                  int T, int Ts, float momentum, ap_float2 *tprev, ap_float2 *rebuilt) {
+    const IDX half = (IDX)(Ts >> 1);
+    const IDX total = (IDX)rows * half;
+    const IDX stride = (IDX)gridDim.x * blockDim.x;
+    for (IDX e = (IDX)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const IDX row = e / half;
+        const int t = (int)(e - row * half) * 2;
+        if (t >= T) continue;
+        const bool two = t + 1 < T;
+        const int64_t w = (int64_t)row * Ts + t, d = (int64_t)row * T + t;
+        const float s0 = S[d], s1 = two ? S[d + 1] : 0.0f;
+        ap_float2 o0, o1;
+        if (angles) {
+            const float a0 = angles[d], a1 = two ? angles[d + 1] : 0.0f;
+            o0 = ap_mk(s0 * cosf(a0), s0 * sinf(a0));
+            o1 = ap_mk(s1 * cosf(a1), s1 * sinf(a1));
+        } else {
+            const ap_float4 c = *reinterpret_cast<const ap_float4 *>(Rcur + w);
+            const ap_float2 u0 = ap_unit_phase(ap_mk(c.x, c.y)), u1 = ap_unit_phase(ap_mk(c.z, c.w));
+            o0 = ap_mk(s0 * u0.x, s0 * u0.y);
+            o1 = ap_mk(s1 * u1.x, s1 * u1.y);
+            if (momentum > 0.0f) {
+                const ap_float4 p = *reinterpret_cast<const ap_float4 *>(Rprev + w);
+                const ap_float2 v0 = ap_unit_phase(ap_mk(p.x, p.y)), v1 = ap_unit_phase(ap_mk(p.z, p.w));
+                o0 = ap_mk(o0.x + momentum * (o0.x - s0 * v0.x), o0.y + momentum * (o0.y - s0 * v0.y));
+                o1 = ap_mk(o1.x + momentum * (o1.x - s1 * v1.x), o1.y + momentum * (o1.y - s1 * v1.y));
+            }
+        }
+        if (two) {
+            ap_float4 o; o.x = o0.x; o.y = o0.y; o.z = o1.x; o.w = o1.y;
+            *reinterpret_cast<ap_float4 *>(rebuilt + w) = o;
+            if (tprev) *reinterpret_cast<ap_float4 *>(tprev + w) = o;
+        } else {
+            rebuilt[w] = o0;
+            if (tprev) tprev[w] = o0;
+        }
+    }
+}
+
+// mean((a - b)^2) in two deterministic passes (griffinlim_iter's reconstruction error, griffinlim.py:268-269):
+// per-workgroup partial sums in float64, then one workgroup adds them in a fixed order.
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
+ap_sqdiff_partial_kernel(const float *a, const float *b, int64_t n, double *part) {
+    __shared__ double red[AP_BLOCK];
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const double d = (double)a[e] - (double)b[e];
+        acc += d * d;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = AP_BLOCK / 2; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
+ap_sum_partials_kernel(const double *part, int n_part, double scale, float *out) {
+    __shared__ double red[AP_BLOCK];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += AP_BLOCK) acc += part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int sft = AP_BLOCK / 2; sft > 0; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] += red[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * scale);
+}
+
 // per-workgroup max of x -> one integer atomic per workgroup on *key (order-preserving key)
-__global__ void __launch_bounds__(AP_BLOCK) ap_reduce_max_kernel(const float *x, int64_t n, unsigned *key) {
+AP_KERNEL void __launch_bounds__(AP_BLOCK) ap_reduce_max_kernel(const float *x, int64_t n, unsigned *key) {
     float *red = reinterpret_cast<float *>(ap_smem);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float m = -INFINITY;
@@ -114,7 +209,7 @@ AP_DEV float ap_db_floor(const ApDbParams &D, float ref) {
     return D.top_db >= 0.0f ? ap_db_value(D, ref, ap_fkey_inv(*D.smax_key)) - D.top_db : -INFINITY;
 }
 
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_to_db_kernel(const float *S, int64_t n, ApDbParams D, float *out) {
     const float ref = ap_db_ref(D);
     const float floor_v = ap_db_floor(D, ref);
@@ -125,7 +220,7 @@ ap_to_db_kernel(const float *S, int64_t n, ApDbParams D, float *out) {
 
 
 // db_to_power / db_to_amplitude (convert.py:100-129, 169-198): ref * 10^(x / div)
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_from_db_kernel(const float *x, int64_t n, float ref, float div, float *out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
@@ -287,7 +382,7 @@ AP_DEV void ap_pcg64_affine(ap_u128 inc, unsigned long long delta, ap_u128 &A, a
     }
 }
 
-__global__ void __launch_bounds__(AP_BLOCK)
+AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_pcg64_uniform_kernel(unsigned long long st_hi, unsigned long long st_lo, unsigned long long inc_hi,
                         unsigned long long inc_lo, double low, double range, int64_t n, float *out) {
 #ifndef AP_HOST_EMU

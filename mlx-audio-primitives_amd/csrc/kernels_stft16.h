@@ -23,6 +23,7 @@
 // of the Griffin-Lim loop): every group's segment is a whole line, no carries.
 #pragma once
 #include "kernels_wave.h"
+#include "kernels_pointwise.h"
 
 #ifdef AP_HOST_EMU
 #define AP_STORE2(p, v, NT) (*(p) = (v))
@@ -34,8 +35,14 @@
     } while (0)
 #endif
 
-template <int PADGEN, int ALIGNED, int NT>
+// GL = 1 (needs ALIGNED = 1): the Griffin-Lim projection rides in the store phase (griffinlim.py:156-178).  Every
+// thread fetches the previous raw spectrum and the target magnitude of ITS 33 elements (99 registers) before
+// the group's first transform - they land under the two transforms - and then stores, per element, the raw bin
+// (next iteration's "previous") and   rebuilt = R' + m (R' - S unit(prev)),  R' = S unit(raw).
+// The separate projection pass over five (B, F, T) arrays and the re-read of the raw spectrum are gone.
+template <int PADGEN, int ALIGNED, int NT, int GL = 0>
 __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApStft16Params P) {
+    static_assert(!GL || ALIGNED, "the fused projection needs the line-padded layout");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = AP_UNIFORM(tid >> 6);
@@ -110,10 +117,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         }
         if (!PADGEN && next_group >= 0) load_frame(next_group, next_second);   // lands under the transform
         AP_SCHED_FENCE();
-        apw_forward<true, !ALIGNED>(v, X, TW1, lc);
+        apw_forward<true, (!ALIGNED || GL)>(v, X, TW1, lc);
         AP_SCHED_FENCE();
         ApwLane ls = lc;
-        if (!ALIGNED) {                      // keeps the 8 split twiddles from being hoisted out of the group loop
+        if (!ALIGNED || GL) {                // keeps the 8 split twiddles from being hoisted out of the group loop
             AP_PIN(ls.tws0h.x);
             AP_PIN(ls.tws0h.y);
         }
@@ -139,6 +146,46 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         const int trem = (int)(P.T - t0);                        // frames t0 + i with i < trem exist
 
         ap_float2 xkA[8], xmA[8], zhA, xkB[8], xmB[8], zhB;
+        ap_float2 gpv[8][4], gpv_mid = ap_mk(0.0f, 0.0f);        // GL: previous raw spectrum of this thread's elements
+        float gmg[8][4], gmg_mid = 0.0f;                          // GL: target magnitudes
+        // the magnitudes of chunks c0 .. c1 - 1 (the first two ride with the previous spectrum before the
+        // transforms, the rest are fetched when the transforms' registers are free again: 25 registers less at the peak)
+        auto gl_load_mag = [&](int c0, int c1) {
+            int sq = sq0, sf = sf0;
+            AP_PIN(sq);
+            AP_PIN(sf);
+            const float *mb = P.gl_mag + b * (int64_t)F * P.T + t0;
+            const bool ok = sf < trem;
+            const int Td = (int)P.T;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c >= c0 && c < c1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int l = sq + 32 * (i & 1);
+                        const int bin = (i >> 1) ? APW_NC - 64 * c - l : 64 * c + l;
+                        gmg[c][i] = ok ? mb[bin * Td + sf] : 0.0f;
+                    }
+                    if (c == 7 && tid < APS16_G) gmg_mid = ok ? mb[(APW_NC / 2) * Td + sf] : 0.0f;
+                }
+        };
+        if (GL) {
+            int sq = sq0, sf = sf0;
+            AP_PIN(sq);
+            AP_PIN(sf);
+            const ap_float2 *pb = P.gl_prev + b * (int64_t)F * P.Ts + t0;
+            const bool ok = sf < trem;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int l = sq + 32 * (i & 1);
+                    const int bin = (i >> 1) ? APW_NC - 64 * c - l : 64 * c + l;
+                    gpv[c][i] = ok ? pb[bin * Ts + sf] : ap_mk(0.0f, 0.0f);
+                }
+            if (tid < APS16_G) gpv_mid = ok ? pb[(APW_NC / 2) * Ts + sf] : ap_mk(0.0f, 0.0f);
+            // (all magnitudes are fetched after the transforms: chunk 0 waits for them, the other chunks do not)
+        }
         if (PADGEN) load_frame(group, 0);
         transform(xkA, xmA, zhA, group, 1);
         if (PADGEN) load_frame(group, 1);
@@ -146,7 +193,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         // the next group's first frame lands under the store phase (during the second transform the
         // registers hold the first frame's spectrum instead)
         AP_SCHED_FENCE();
-        if (!PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
+        if (GL) gl_load_mag(0, 8);
+        // (GL: the projection's operands fill the registers until half of the chunks are out: the prefetch waits)
+        if (!GL && !PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
         AP_SCHED_FENCE();
 
         // ---- transposed store: chunk c holds bins 64 c + lane and 1024 - 64 c - lane ----------
@@ -167,6 +216,11 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                 buf[128 * APS16_OB_ROW + 8 + wave] = ap_mk(zhB.x, -zhB.y);
             }
             AP_LDS_BARRIER();
+            if (GL && c == 4) {
+                AP_SCHED_FENCE();
+                if (!PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
+                AP_SCHED_FENCE();
+            }
             // thread (sq = tid / 16, sf = tid % 16) owns position sf of the windows of the chunk's rows
             // sq, 32 + sq (bins 64 c + l) and 64 + sq, 96 + sq (bins 1024 - 64 c - l), l = sq, 32 + sq
             int bins[5], slots[5];
@@ -189,6 +243,17 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                     if (i < ne) {
                         const bool mine = i < 4 || tid < APS16_G;
                         if (mine && sf < trem) AP_STORE2(&ob[bins[i] * Ts + sf], x[i], NT);
+                        if (GL && mine && sf < trem) {
+                            // the arithmetic of ap_gl_rows_kernel (kernels_pointwise.h), operation for operation
+                            const float sm = i < 4 ? gmg[c][i] : gmg_mid;
+                            const ap_float2 u = ap_unit_phase(x[i]);
+                            ap_float2 rn = ap_mk(sm * u.x, sm * u.y);
+                            if (P.gl_momentum > 0.0f) {
+                                const ap_float2 v = ap_unit_phase(i < 4 ? gpv[c][i] : gpv_mid);
+                                rn = ap_mk(rn.x + P.gl_momentum * (rn.x - sm * v.x), rn.y + P.gl_momentum * (rn.y - sm * v.y));
+                            }
+                            P.gl_rebuilt[b * (int64_t)F * P.Ts + t0 + bins[i] * Ts + sf] = rn;
+                        }
                     }
             } else {
                 // One LDS read per element: frame (sf + phi) mod 16 of this group is either stored now

@@ -6,9 +6,9 @@
 #include "ap_tu.h"
 #include "kernels_stft16.h"
 
-template <int PADGEN, int ALIGNED, int NT>
+template <int PADGEN, int ALIGNED, int NT, int GL = 0>
 static int ap_stft16_go(const ApStft16Params &W, int grid, void *stream) {
-    auto kern = ap_stft2048_g16_kernel<PADGEN, ALIGNED, NT>;
+    auto kern = ap_stft2048_g16_kernel<PADGEN, ALIGNED, NT, GL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, W.lds_bytes);
     if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipFuncSetAttribute(LDS=%d): %s", W.lds_bytes, hipGetErrorString(e));
@@ -36,4 +36,20 @@ int ap_launch_stft16(const ApStftParams &P, int64_t B, int64_t Ts, void *stream)
     }
     if (pg) return nt ? ap_stft16_go<1, 0, 1>(W, grid, stream) : ap_stft16_go<1, 0, 0>(W, grid, stream);
     return nt ? ap_stft16_go<0, 0, 1>(W, grid, stream) : ap_stft16_go<0, 0, 0>(W, grid, stream);
+}
+
+// STFT of y with the Griffin-Lim projection in its store phase (kernels_stft16.h, GL = 1): raw spectrum -> P.out_c,
+// new estimate -> rebuilt; both and `prev` in rows Ts apart (Ts % 16 == 0, 128-byte aligned), `mag` dense.
+int ap_launch_stft16_gl(const ApStftParams &P, int64_t B, int64_t Ts, const float *prev, const float *mag, float momentum,
+                        float *rebuilt, void *stream) {
+    ApStft16Params W;
+    int grid = 0, aligned = 0;
+    if (ap_prepare_stft16(W, P, B, Ts, &grid, &aligned) != AP_OK) return 1;
+    if (!aligned || ((reinterpret_cast<uintptr_t>(prev) | reinterpret_cast<uintptr_t>(rebuilt)) & 127)) return 1;
+    W.gl_prev = reinterpret_cast<const ap_float2 *>(prev);
+    W.gl_mag = mag;
+    W.gl_rebuilt = reinterpret_cast<ap_float2 *>(rebuilt);
+    W.gl_momentum = momentum;
+    if (!ap_clip_loads_ok(W)) return ap_stft16_go<1, 1, 0, 1>(W, grid, stream);
+    return ap_stft16_go<0, 1, 0, 1>(W, grid, stream);
 }

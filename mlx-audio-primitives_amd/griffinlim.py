@@ -18,7 +18,7 @@ import torch
 
 from . import _extension as _x
 from ._validation import validate_positive, validate_range
-from .stft import istft, stft
+from .stft import istft, magnitude, phase, stft
 
 
 def _random_phase(random_state, shape, device) -> torch.Tensor:
@@ -88,14 +88,75 @@ def griffinlim(S, n_iter: int = 32, hop_length: int | None = None, win_length: i
     TR = _frame_count(y_len, n_fft, hop_length, center, pad_mode)
     win = _get_padded_window(window, win_length, n_fft, dev)
     tw = _get_twiddles(n_fft, dev)
+    y = torch.empty((B, y_len), dtype=torch.float32, device=dev)
+    if n_fft == 2048 and TR == T and _x.lib().ap_istft_workspace_floats(B, T, 2048, int(hop_length), pad) == 0:
+        # n_fft = 2048: the three complex workspaces live with their rows padded to whole 128-byte lines
+        # (16 frames), which the STFT kernel then writes and the ISTFT kernel reads without straddling lines
+        Ts = -(-T // 16) * 16
+        ws3 = torch.empty((3, B, F, Ts, 2), dtype=torch.float32, device=dev)
+        rc = _x.dlib(dev).ap_griffinlim_rows_f32(
+            _x.ptr(S), _x.ptr(angles), B, T, Ts, int(n_fft), int(hop_length), _x.ptr(win), _x.ptr(tw),
+            int(bool(center)), _x.PAD_MODES[pad_mode], pad, y_len, int(n_iter), float(momentum),
+            _x.ptr(ws3[0]), _x.ptr(ws3[1]), _x.ptr(ws3[2]), _x.ptr(y), _x.stream_ptr(dev))
+        if rc != _x.AP_ERR_UNSUPPORTED:
+            _x.check(rc)
+            return y if batched else y[0]
     rebuilt = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
     tprev = torch.empty((B, F, T, 2), dtype=torch.float32, device=dev)
     R = torch.empty((B, F, TR, 2), dtype=torch.float32, device=dev)
     n_ws = int(_x.lib().ap_istft_workspace_floats(B, T, int(n_fft), int(hop_length), pad))
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
-    y = torch.empty((B, y_len), dtype=torch.float32, device=dev)
     _x.check(_x.dlib(dev).ap_griffinlim_f32(
         _x.ptr(S), _x.ptr(angles), B, T, int(n_fft), int(hop_length), _x.ptr(win), _x.ptr(tw),
         int(bool(center)), _x.PAD_MODES[pad_mode], pad, y_len, TR, int(n_iter), float(momentum),
         _x.ptr(rebuilt), _x.ptr(tprev), _x.ptr(R), _x.ptr(ws), _x.ptr(y), _x.stream_ptr(dev)))
     return y if batched else y[0]
+
+
+def griffinlim_iter(S, angles, hop_length: int, win_length: int, n_fft: int, window="hann", center: bool = True,
+                    pad_mode: str = "constant", momentum: float = 0.99, tprev=None):
+    """One Griffin-Lim iteration (reference griffinlim.py:199-284), for custom stopping criteria.
+
+    Returns ``(new_angles, new_rebuilt, error)``: the phase of stft(istft(S exp(i angles))), the
+    magnitude-constrained estimate S exp(i new_angles) with the momentum term ``+ momentum * (. - tprev)``
+    when ``tprev`` is given, and the reconstruction error mean((S - |stft(istft(.))|)**2) as a 0-d tensor.
+    Built from the library's own entry points: ap_gl_project_f32 (both projections), the fused istft / stft
+    kernels, ap_magnitude / ap_phase and the deterministic ap_mse_f32 reduction."""
+    S = _x.to_device_f32(S)
+    batched = S.ndim == 3
+    if S.ndim not in (2, 3):
+        raise ValueError(f"S must be 2D or 3D, got {S.ndim}D")
+    S3 = (S if batched else S[None]).contiguous()
+    dev = S3.device
+    ang = _x.to_device_f32(angles, dev)
+    ang3 = (ang if ang.ndim == 3 else ang[None]).contiguous()
+    if ang3.shape != S3.shape:
+        raise ValueError(f"angles must have the shape of S, got {tuple(ang.shape)} and {tuple(S.shape)}")
+    B, F, T = S3.shape
+    rebuilt = torch.empty((B, F, T), dtype=torch.complex64, device=dev)
+    _project(0, S3, ang3, None, 0.0, None, rebuilt)                     # S exp(i angles)
+    y_est = istft(rebuilt, hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window, center=center)
+    R = stft(y_est, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center,
+             pad_mode=pad_mode)
+    if R.shape != S3.shape:            # the reference's S - mag_new fails to broadcast on the same mismatch
+        raise ValueError(f"stft of the estimate has shape {tuple(R.shape)}, S has {tuple(S3.shape)}")
+    mag_new = magnitude(R)
+    new_angles = phase(R)
+    ws = torch.empty(int(_x.lib().ap_mse_workspace_doubles()), dtype=torch.float64, device=dev)
+    err = torch.empty(1, dtype=torch.float32, device=dev)
+    _x.check(_x.dlib(dev).ap_mse_f32(_x.ptr(S3), _x.ptr(mag_new), S3.numel(), _x.ptr(ws), _x.ptr(err),
+                                     _x.stream_ptr(dev)))
+    Rd = R.contiguous()
+    out = torch.empty((B, F, T), dtype=torch.complex64, device=dev)
+    if momentum > 0 and tprev is not None:
+        tp = tprev if isinstance(tprev, torch.Tensor) else torch.as_tensor(np.asarray(tprev))
+        tp = tp.to(device=dev, dtype=torch.complex64)
+        tp = (tp if tp.ndim == 3 else tp[None]).clone().contiguous()    # the projection kernel updates its tprev in place
+        if tp.shape != S3.shape:
+            raise ValueError(f"tprev must have the shape of S, got {tuple(tp.shape)}")
+        _project(1, S3, None, Rd, momentum, tp, out)
+    else:
+        _project(1, S3, None, Rd, 0.0, None, out)
+    if not batched:
+        new_angles, out = new_angles[0], out[0]
+    return new_angles, out, err[0]
