@@ -358,6 +358,7 @@ static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bo
     W.max_key = nullptr;
     W.L = P.L;
     W.T = P.T;
+    W.Ts = P.T;                                            // dense rows; the padded-row entry points overwrite it
     W.n_clips = B;
     W.groups_per_clip = (P.T + 7) / 8;
     W.n_groups = W.groups_per_clip * B;
@@ -431,6 +432,7 @@ static inline int ap_prepare_istft8(W8 &W, const float *S, const float *tw, int6
     W.window = window;
     W.y = y;
     W.T = T;
+    W.Ts = T;                                              // dense rows; ap_istft_rows_f32 overwrites it
     W.n_clips = B;
     W.groups_per_clip = (T + 7) / 8;
     W.n_groups = W.groups_per_clip * B;

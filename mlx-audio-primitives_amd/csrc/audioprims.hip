@@ -144,11 +144,15 @@ static int ap_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *plan,
 }
 
 template <int R>
-static int ap_launch_stft8(const ApStftParams &P, int64_t B, void *stream, bool *handled) {
+static int ap_launch_stft8(const ApStftParams &P, int64_t B, void *stream, bool *handled, int64_t Ts = 0) {
     ApFrames8Params W;
     int grid = 0;
     *handled = false;
     if (ap_prepare_frames8(W, P, B, false, nullptr, nullptr, APQ_WAVES, ap_frames8_geom<R>(), &grid) != AP_OK) return AP_OK;
+    if (Ts > 0) {                                          // padded rows: a clip's rows still have to fit 32-bit offsets
+        if (Ts < P.T || Ts > (1 << 19)) return AP_OK;
+        W.Ts = Ts;
+    }
     auto kern = ap_clip_loads_ok(P) ? ap_stft8_wave_kernel<R, 0> : ap_stft8_wave_kernel<R, 1>;
     int rc = ap_allow_lds(kern, W.lds_bytes);
     if (rc != AP_OK) return rc;
@@ -307,12 +311,21 @@ int ap_stft_rows_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, c
     if (row_stride == T) return ap_stft_f32(y, B, L, n_fft, hop, window, tw, center, pad_mode, T, out, stream);
     if (row_stride < T) AP_FAIL(AP_ERR_INVALID, "stft: row_stride (%lld) must be >= the number of frames (%lld)",
                                 (long long)row_stride, (long long)T);
-    if (n_fft != 2048) AP_FAIL(AP_ERR_UNSUPPORTED, "stft: padded rows are served for n_fft = 2048 only");
+    if (n_fft != 2048 && n_fft != 512 && n_fft != 400 && n_fft != 256)
+        AP_FAIL(AP_ERR_UNSUPPORTED, "stft: padded rows are served for n_fft = 2048, 512, 400 and 256 only");
     ApStftParams P;
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
     if (!out) AP_FAIL(AP_ERR_INVALID, "stft: NULL output");
     P.out_c = reinterpret_cast<ap_float2 *>(out);
+    if (n_fft != 2048) {                                   // eight frames per wave (kernels_frames8.h): 64-byte runs
+        bool handled = false;
+        rc = n_fft == 400 ? ap_launch_stft8<25>(P, B, stream, &handled, row_stride)
+             : n_fft == 512 ? ap_launch_stft8<32>(P, B, stream, &handled, row_stride)
+                            : ap_launch_stft8<16>(P, B, stream, &handled, row_stride);
+        if (rc != AP_OK || handled) return rc;
+        AP_FAIL(AP_ERR_UNSUPPORTED, "stft: shape not served with padded rows");
+    }
     rc = ap_launch_stft16(P, B, row_stride, stream);
     if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "stft: shape not served with padded rows");
     return rc;
@@ -512,7 +525,23 @@ int ap_istft_rows_f32(const float *S, int64_t B, int64_t T, int64_t row_stride, 
     if (!S || !tw || !window || !out) AP_FAIL(AP_ERR_INVALID, "istft: NULL buffer");
     if (row_stride < T) AP_FAIL(AP_ERR_INVALID, "istft: row_stride (%lld) must be >= the number of frames (%lld)",
                                 (long long)row_stride, (long long)T);
-    if (n_fft != 2048 || hop <= 0 || out_len <= 0) AP_FAIL(AP_ERR_UNSUPPORTED, "istft: padded rows are served for n_fft = 2048 only");
+    if (hop <= 0 || out_len <= 0) AP_FAIL(AP_ERR_UNSUPPORTED, "istft: bad hop / length");
+    if (n_fft == 512 || n_fft == 400 || n_fft == 256) {    // fused ISTFT of the frames8 family
+        ApIstft8Params W;
+        int grid = 0;
+        if (B > 0 && row_stride <= (1 << 19) &&
+            ap_prepare_istft8(W, S, tw, B, T, n_fft, window, hop, out_offset, out_len, out, APQ_WAVES, &grid) == AP_OK) {
+            W.Ts = row_stride;
+            auto kern = n_fft == 512 ? ap_istft8_wave_kernel<32> : n_fft == 400 ? ap_istft8_wave_kernel<25>
+                                                                                 : ap_istft8_wave_kernel<16>;
+            int rc0 = ap_allow_lds(kern, W.lds_bytes);
+            if (rc0 != AP_OK) return rc0;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APQ_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+            return ap_check_launch("ap_istft_rows_f32(fused frames8)");
+        }
+        AP_FAIL(AP_ERR_UNSUPPORTED, "istft: shape not served with padded rows");
+    }
+    if (n_fft != 2048) AP_FAIL(AP_ERR_UNSUPPORTED, "istft: padded rows are served for n_fft = 2048, 512, 400 and 256 only");
     const int rc = ap_launch_istft16(S, tw, B, T, row_stride, window, hop, out_offset, out_len, out, stream);
     if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "istft: shape not served with padded rows (hop must divide 2048, hop >= 256)");
     return rc;

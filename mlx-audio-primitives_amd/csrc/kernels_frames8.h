@@ -53,6 +53,7 @@ struct ApFrames8Params {
     float *out;                // mel: (B, M, T); STFT: (B, n_fft/2 + 1, T) complex64
     unsigned *max_key;
     int64_t L, T, n_clips, groups_per_clip, n_groups;
+    int64_t Ts;                // STFT: complex values between the rows of `out` (T = dense; a multiple of 16 = whole lines)
     int hop, pad, pad_mode, n_mels, wmax;   // pad_mode: used by the PADGEN instantiations only.   wmax: floats per filter row of the LDS weight table (32 or 64, + 4 for even R)
     float power;
     int off_t, off_s, off_win, off_w, off_lo, off_plane, lds_bytes;
@@ -437,15 +438,16 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_stft8_wave_kernel(ApFram
     const int Ti = (int)P.T;
     // One clip's output rows as a bounds-checked buffer (the launch code keeps them under 2 GiB): the
     // lane part of a store's address is (bin block R k2, frame g), the uniform part (bin k1, group t0).
-    const unsigned lane_bytes = 8u * ((unsigned)(R * Ln.k2) * (unsigned)Ti + (unsigned)Ln.g);
-    const int64_t clip_bytes = (int64_t)(NC + 1) * P.T * 8;
+    const int Tsi = (int)P.Ts;                                                  // row stride (T, or padded to whole lines)
+    const unsigned lane_bytes = 8u * ((unsigned)(R * Ln.k2) * (unsigned)Tsi + (unsigned)Ln.g);
+    const int64_t clip_bytes = (int64_t)(NC + 1) * P.Ts * 8;
     apq_group_loop<R, PADGEN>(P, Ln, Tt + Ln.q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
         const ApOutBuf ob = ap_outbuf_make(reinterpret_cast<char *>(P.out) + b * clip_bytes, clip_bytes);
         const unsigned lb = t0 + Ln.g < Ti ? lane_bytes : 0xF0000000u;          // frames past T: parked
         apq_split<R>(v, St + Ln.q * BS, Ln, [&](int k1, ap_float2 x) {
-            ap_outbuf_store2(ob, lb, 8u * (unsigned)(k1 * Ti + t0), x);
+            ap_outbuf_store2(ob, lb, 8u * (unsigned)(k1 * Tsi + t0), x);
         });
-        if (Ln.q == 0) ap_outbuf_store2(ob, lb, 8u * (unsigned)(NC * Ti + t0), ap_mk(v[0].x - v[0].y, 0.0f));   // bin 8R
+        if (Ln.q == 0) ap_outbuf_store2(ob, lb, 8u * (unsigned)(NC * Tsi + t0), ap_mk(v[0].x - v[0].y, 0.0f));   // bin 8R
     });
 }
 
@@ -569,6 +571,7 @@ struct ApIstft8Params {
     const float *window;       // (16 R)
     float *y;                  // (B, out_len)
     int64_t T, n_clips, groups_per_clip, n_groups, out_offset, out_len;
+    int64_t Ts;                // complex values between the rows of S (T = dense)
     int hop, span;             // span = 7 hop + n_fft
     int off_t, off_s, off_w2, off_wss, off_acc, lds_bytes;
 };
@@ -614,8 +617,9 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_istft8_wave_kernel(ApIst
         wv[k1] = ap_mk(w.x * sc, -w.y * sc);
     }
     AP_LDS_BARRIER();
-    const int64_t clip_bytes = (int64_t)(NC + 1) * P.T * 8;
-    const unsigned lane_bytes = 8u * ((unsigned)q * (unsigned)Ti + (unsigned)g);
+    const int Tsi = (int)P.Ts;                                                  // row stride of S
+    const int64_t clip_bytes = (int64_t)(NC + 1) * P.Ts * 8;
+    const unsigned lane_bytes = 8u * ((unsigned)q * (unsigned)Tsi + (unsigned)g);
     const int n_carry = N - hop;                                                // samples a group hands on
     const int n_round = (N + hop - 1) / hop < 8 ? (N + hop - 1) / hop : 8;
 
@@ -633,7 +637,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_istft8_wave_kernel(ApIst
         const bool last = t0 + 8 >= Ti;                                         // last group of its clip
         const ApOutBuf sb = ap_outbuf_make(const_cast<char *>(reinterpret_cast<const char *>(P.S)) + b * clip_bytes, clip_bytes);
         ap_float2 v[R];
-        apq_inverse_frame<R>(sb, live ? lane_bytes : 0xF0000000u, Ti, t0, Sm + q * BS, Tt + q * BS, Ln, msrc, v);
+        apq_inverse_frame<R>(sb, live ? lane_bytes : 0xF0000000u, Tsi, t0, Sm + q * BS, Tt + q * BS, Ln, msrc, v);
         // Overlap-add into the accumulator in n_round = ceil(N / hop) rounds: frames n_round apart do not overlap,
         // so round r adds the frames g = r (mod n_round) with plain read-add-write (LDS float atomics cost ~150
         // cycles per wave instruction here: 1.0 ms of a 1.5 ms kernel).  8-byte accesses when hop is even.

@@ -114,7 +114,7 @@ def _frame_count(signal_length: int, n_fft: int, hop_length: int, center: bool, 
     return 1 + (padded - n_fft) // hop_length
 
 
-# Layout of the spectrum `stft` returns for n_fft = 2048.  "lines" (default): the (…, F, T) result is a strided
+# Layout of the spectrum `stft` returns for n_fft = 2048 / 512 / 400 / 256.  "lines" (default): the (…, F, T) result is a strided
 # VIEW of a buffer whose rows are padded to a multiple of 16 frames, so every row starts on a 128-byte line and
 # the kernel writes whole lines (0.28 instead of 0.36 ms on 256 x 10 s; `istft`, `magnitude`, `phase` and
 # `griffinlim` read such views in place).  The values, shape and dtype are the reference's; only
@@ -122,6 +122,7 @@ def _frame_count(signal_length: int, n_fft: int, hop_length: int, center: bool, 
 # mx.transpose(…, (0, 2, 1)) of its (B, T, F) transform (stft.py:216).  "dense": a contiguous array
 # (what the C entry point ap_stft_f32 always writes).
 _SPECTRUM_LAYOUT = "lines"
+_LINES_N_FFT = (2048, 512, 400, 256)       # the kernels that write / read padded rows (ap_stft_rows_f32, ap_istft_rows_f32)
 
 
 def set_spectrum_layout(layout: str) -> str:
@@ -153,7 +154,8 @@ def stft(y, n_fft: int = 2048, hop_length: int | None = None, win_length: int | 
     T = _frame_count(L, n_fft, hop_length, center, pad_mode)
     F = n_fft // 2 + 1
     Ts = T
-    if n_fft == 2048 and _SPECTRUM_LAYOUT == "lines" and T % 16 and B > 0 and L > 0 and B * T >= 512:
+    if n_fft in _LINES_N_FFT and _SPECTRUM_LAYOUT == "lines" and T % 16 and B > 0 and L > 0 and B * T >= 512 \
+            and T < (1 << 19) - 16:
         Ts = -(-T // 16) * 16                # rows padded to whole 128-byte lines (see _SPECTRUM_LAYOUT)
     out = torch.empty((B, F, Ts, 2), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
@@ -234,7 +236,7 @@ def istft(stft_matrix, hop_length: int | None = None, win_length: int | None = N
     # rows padded to whole 128-byte lines (stft_padded_rows / ap_stft_rows_f32) are read in place by the
     # fused n_fft = 2048 kernel; every other strided view is made dense first
     row_stride = _padded_row_stride(S)
-    if row_stride is None or F != 1025 or (n_fft is not None and n_fft != 2048):
+    if row_stride is None or 2 * (F - 1) not in _LINES_N_FFT or (n_fft is not None and n_fft != 2 * (F - 1)):
         S = S.contiguous()
         row_stride = None
     if n_fft is None:

@@ -249,3 +249,28 @@ def test_stft_lines_layout_is_a_view_with_the_dense_values():
     assert torch.equal(V.contiguous(), D)
     with pytest.raises(ValueError, match="Unknown spectrum layout"):
         stft_mod.set_spectrum_layout("columns")
+
+
+@pytest.mark.parametrize("n_fft,hop,L,B", [(512, 128, 30000, 6), (400, 160, 48000, 5), (256, 64, 20000, 4), (512, 100, 9000, 9)])
+def test_lines_layout_of_the_eight_frame_kernels(n_fft, hop, L, B):
+    """n_fft = 512 / 400 / 256 (kernels_frames8.h): padded rows give the dense rows' bits, the fused ISTFT reads
+    them in place, and both match the oracle."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    yd = dev(y)
+    stft_mod.set_spectrum_layout("dense")
+    try:
+        D = ap.stft(yd, n_fft=n_fft, hop_length=hop)
+        assert D.is_contiguous()
+    finally:
+        stft_mod.set_spectrum_layout("lines")
+    V = ap.stft(yd, n_fft=n_fft, hop_length=hop)
+    if D.shape[-1] % 16:
+        assert not V.is_contiguous() and V.stride(1) % 16 == 0
+    assert torch.equal(torch.view_as_real(V), torch.view_as_real(D))
+    np.testing.assert_allclose(host(V), ao.stft(y, n_fft=n_fft, hop_length=hop), rtol=1e-4, atol=1e-4)
+    a, b = ap.istft(V, hop_length=hop, length=L), ap.istft(D, hop_length=hop, length=L)
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(host(a), ao.istft(host(D), hop_length=hop, n_fft=n_fft, length=L), atol=1e-5)
+    if n_fft % hop == 0:
+        assert np.max(np.abs(host(a) - y)) < 1e-5
