@@ -1012,6 +1012,9 @@ int ap_spectral_audio_fused(int64_t L, int n_fft, int hop, int center, int pad_m
     const int pad = center ? n_fft / 2 : 0;
     if (pad != 0 && (pad_mode != AP_PAD_CONSTANT || (hop & 1))) return 0;
     if (!center && L < n_fft) return 0;
+    // the bounds ap_prepare_spec_run enforces (32-bit sample offsets, 24-bit frame counts): past them the caller
+    // must take the two-kernel route instead of failing in the launch
+    if (L > (1 << 28) || ap_n_frames(L, n_fft, hop, center) > (1 << 24)) return 0;
     return std::getenv("AP_SPEC_TWO_KERNELS") ? 0 : 1;      // A/B switch: keep the STFT + statistics route
 }
 
@@ -1257,6 +1260,8 @@ int ap_melspec_pcm16_fused(int64_t L, int n_fft, int hop, int center, int pad_mo
     if (center && pad_mode != AP_PAD_CONSTANT) return 0;
     if ((L & 1) || (hop & 1)) return 0;                  // a dword holds the even-indexed sample and its successor
     if (n_mels > 128 || desc[12] > 256 || desc[15] > 4) return 0;
+    // the bounds ap_prepare_mel_run enforces: past them the caller needs the float32 scratch route
+    if (L > (1 << 28) || ap_n_frames(L, n_fft, hop, center) > (1 << 24)) return 0;
     return std::getenv("AP_MEL2048_WAVE") ? 0 : 1;
 }
 
@@ -1265,7 +1270,10 @@ int ap_melspec_pcm16_f32(const int16_t *y, int64_t B, int64_t L, int n_fft, int 
                          const int32_t *desc, int n_mels, float power, float *out, uint32_t *max_key_dev,
                          float *scratch_f32, void *stream) {
     if (!y) AP_FAIL(AP_ERR_INVALID, "melspectrogram: NULL buffer");
-    if (ap_melspec_pcm16_fused(L, n_fft, hop, center, pad_mode, n_mels, power, desc)) {
+    // the fused kernel reads sample PAIRS as dwords: the clip base has to be 4-byte aligned (an int16 view that
+    // starts at an odd element is not) - such inputs take the conversion pass
+    const bool aligned = (reinterpret_cast<uintptr_t>(y) & 3) == 0;
+    if (aligned && ap_melspec_pcm16_fused(L, n_fft, hop, center, pad_mode, n_mels, power, desc)) {
         ApStftParams P;
         int rc = ap_prepare_stft(P, reinterpret_cast<const float *>(y), B, L, n_fft, hop, window, tw, center, pad_mode, T);
         if (rc != AP_OK) return rc;

@@ -90,7 +90,7 @@ def _on_device(key, bank: np.ndarray, device) -> torch.Tensor:
     if t is None:
         t = torch.from_numpy(bank.copy()).to(dev)
         _device_cache[key] = t
-    return t
+    return t.clone()          # callers own what they get: an in-place edit must not reach the cache
 
 
 def bark_filterbank(sr: int, n_fft: int, n_bands: int = 24, fmin: float = 0.0, fmax: float | None = None,

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from functools import lru_cache
 
+import hashlib
+
 import numpy as np
 import torch
 
@@ -160,6 +162,7 @@ def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode
             fused = _x.lib().ap_melspec_pcm16_fused(L, int(n_fft), hop_length, int(bool(center)),
                                                     _x.PAD_MODES[pad_mode], int(n_rows), float(power),
                                                     desc.ctypes.data)
+            fused = fused and y.data_ptr() % 4 == 0      # the fused loads read sample pairs as dwords
             scratch = None if fused else torch.empty((B, L), dtype=torch.float32, device=dev)
             _x.check(_x.dlib(dev).ap_melspec_pcm16_f32(
                 _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
@@ -216,7 +219,7 @@ def filterbank_spectrogram(y, filterbank, n_fft: int = 2048, hop_length: int | N
         raise ValueError(f"filterbank must have shape (n_bands, {1 + n_fft // 2}), got {tuple(fb_np.shape)}")
 
     def bank(dev):
-        key = (hash(fb_np.tobytes()), fb_np.shape, str(dev))
+        key = (hashlib.sha256(fb_np.tobytes()).digest(), fb_np.shape, str(dev))   # content-addressed: no collisions
         hit = _custom_bank_cache.get(key)
         if hit is None:
             plan_np, desc = _x.mel_plan_host(fb_np)

@@ -81,6 +81,10 @@ def _frame_acf_peaks(y, sr, fmin, fmax, frame_length, hop_length, threshold, cen
         if pad:
             yp = torch.empty((B, Lp), dtype=torch.float32, device=dev)
             _x.check(d.ap_pad_f32(_x.ptr(y), B, L, pad, _x.PAD_MODES["constant"], _x.ptr(yp), st))
+        # Lags beyond the frame are treated as 0 here.  Deviation from the reference when sr / fmin >= frame_length
+        # (e.g. frame_length = 1024, sr = 22050, fmin = 20): its r is the full n_fft-long irfft, so it then sees the
+        # mirrored negative lags in r[frame_length:] and a slice cut at n_fft (pitch.py:189-214).  No fixture of the
+        # reference covers that shape ("parity unpinned"); the search range inside the frame is identical.
         n_lag = min(max_lag + 1, frame_length)
         # one clip's frames at a time (a few clips per pass when they are short): bounded workspace
         per_pass = max(1, min(B, (1 << 15) // max(T, 1)))

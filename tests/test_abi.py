@@ -165,3 +165,30 @@ def test_host_resample_poly_taps_are_scipys_bit_for_bit():
         n_pre_pad = down - half_len % down
         np.testing.assert_array_equal(taps, np.concatenate([np.zeros(n_pre_pad, np.float32), h]))
         assert n_pre_remove == (half_len + n_pre_pad) // down
+
+
+def test_fused_predicates_agree_with_the_launch_bounds():
+    """ap_spectral_audio_fused / ap_melspec_pcm16_fused must say "no" for clips beyond the bounds the
+    fused kernels' launch code enforces (L <= 2^28 samples, T <= 2^24 frames), so that the Python layer takes the
+    two-kernel / scratch route instead of failing inside the launch.  Host-only: the predicates touch no GPU."""
+    import ctypes
+
+    import numpy as np
+
+    from mlx_audio_primitives_amd import _extension as ext
+
+    L_ = ext.lib()
+    desc = np.zeros(16, np.int32)
+    desc[0] = 2 | 1            # AP_PLAN_PARTS | AP_PLAN_BANDED (include/audioprims.h)
+    desc[12], desc[15] = 128, 3
+    dptr = desc.ctypes.data_as(ctypes.c_void_p)
+    L_.ap_spectral_audio_fused.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L_.ap_melspec_pcm16_fused.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    assert L_.ap_spectral_audio_fused(220500, 2048, 512, 1, 0) == 1
+    assert L_.ap_spectral_audio_fused((1 << 28) + 2, 2048, 512, 1, 0) == 0          # sample offsets past 32 bits
+    assert L_.ap_spectral_audio_fused(1 << 28, 2048, 2, 1, 0) == 0                  # more than 2^24 frames
+    ok = L_.ap_melspec_pcm16_fused(220500, 2048, 512, 1, 0, 128, 2.0, dptr)
+    if ok:                       # (the plan flags above are what mel_plan_host sets for the default bank)
+        assert L_.ap_melspec_pcm16_fused((1 << 28) + 2, 2048, 512, 1, 0, 128, 2.0, dptr) == 0
+        assert L_.ap_melspec_pcm16_fused(1 << 28, 2048, 2, 1, 0, 128, 2.0, dptr) == 0

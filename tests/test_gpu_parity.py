@@ -162,7 +162,12 @@ def test_stft_extreme_and_mixed_radix(n_fft, hop):
     S = ap.stft(dev(y), n_fft=n_fft, hop_length=hop)
     R = ao.stft(y, n_fft=n_fft, hop_length=hop)
     assert S.shape == R.shape
-    np.testing.assert_allclose(host(S), R, rtol=1e-4, atol=2e-4)
+    # the reference's bar, rtol = atol = 1e-4 (tests/test_stft.py:28-59), for every n_fft it tests (<= 4096,
+    # test_mathematical_properties.py:360-405).  n_fft = 8192: a float32 transform of N unit-variance samples has
+    # bins of size ~sqrt(N) = 90 and carries an rms rounding error of ~eps sqrt(N log2 N) = 4e-5 with tails past
+    # 1e-4 next to bins near zero (where rtol gives nothing), so the absolute term scales with sqrt(N / 4096).
+    atol = 1e-4 if n_fft <= 4096 else 1e-4 * float(np.sqrt(n_fft / 4096.0))
+    np.testing.assert_allclose(host(S), R, rtol=1e-4, atol=atol)
 
 
 def test_stft_matches_torch_golden():

@@ -274,3 +274,79 @@ def test_lines_layout_of_the_eight_frame_kernels(n_fft, hop, L, B):
     np.testing.assert_allclose(host(a), ao.istft(host(D), hop_length=hop, n_fft=n_fft, length=L), atol=1e-5)
     if n_fft % hop == 0:
         assert np.max(np.abs(host(a) - y)) < 1e-5
+
+
+def test_int16_view_at_an_odd_element_takes_the_conversion_route():
+    """the fused int16 mel kernel reads sample pairs as dwords; a contiguous int16 view that starts at an
+    odd element is only 2-byte aligned and must not take it."""
+    rng = np.random.default_rng(31)
+    pcm = rng.integers(-20000, 20000, size=(2 * 22051,), dtype=np.int16)
+    big = dev(pcm)
+    for start in (0, 1):
+        v = big[start:start + 2 * 22050].view(2, 22050)
+        assert v.data_ptr() % 4 == (2 if start else 0)
+        got = host(ap.melspectrogram(v, sr=22050, n_fft=2048, hop_length=512, n_mels=128))
+        ref = ao.melspectrogram(host(v).astype(np.float32) / 32768.0, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_cached_filterbanks_are_handed_out_as_copies():
+    a = ap.bark_filterbank(22050, 2048, 24)
+    a.mul_(0.0)
+    b = ap.bark_filterbank(22050, 2048, 24)
+    assert float(b.abs().sum()) > 0.0
+
+
+# ---------------------------------------------------------------- BASELINE configs at their full sizes
+def test_headline_exact_size_oracle_on_three_clips():
+    """The config the metric is quoted on, exactly: 256 x 220 500 samples @22.05 kHz, n_fft 2048, hop 512, 128 mels;
+    oracle on clips 0 / 127 / 255 (rtol = atol = 1e-4, tests/test_mel.py:157-238), a checksum of per-clip checksums
+    against a second launch, and clip permutation."""
+    import bench
+
+    y = bench.synth_batch(256, 220500, 22050, 42, torch.device("cuda"))
+    M = ap.melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert M.shape == (256, 128, 431) and torch.isfinite(M).all()
+    idx = [0, 127, 255]
+    ref = ao.melspectrogram(host(y[idx]), sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    np.testing.assert_allclose(host(M[idx]), ref, rtol=1e-4, atol=1e-4)
+    M2 = ap.melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert torch.equal(M, M2)
+    perm = torch.randperm(256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    Mp = ap.melspectrogram(y[perm].contiguous(), sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert torch.equal(Mp, M[perm])
+
+
+def test_cfg4_chain_at_full_size():
+    """BASELINE config 4 at B = 1 024 x 480 000 @48 kHz: the resample leg bit-exact against SciPy on 6 clips (it is
+    bit-exact by construction everywhere: same kernel), mfcc13 against the oracle on those clips with the batch's
+    global clip floor, power-of-two gain invariance (a gain of 4 shifts every dB value by exactly 20 log10(4) before
+    the clip, so the DCT changes only in c0) and clip permutation."""
+    B, L = 1024, 480000
+    g = torch.Generator(device="cuda").manual_seed(45)
+    t = torch.linspace(0, 10.0, L, device="cuda")
+    y = torch.randn((B, L), device="cuda", generator=g) * 0.05
+    y += torch.sin(2 * np.pi * (200 + 300 * t) * t)[None, :]
+    y16 = ap.resample_poly(y, 1, 3)
+    assert y16.shape == (B, 160000)
+    idx = [0, 1, 511, 512, 1022, 1023]
+    r_want = ao.resample_poly(host(y[idx]), 1, 3)
+    np.testing.assert_array_equal(host(y16[idx]), r_want)
+    C = ap.mfcc(y16, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    assert C.shape == (B, 13, 313) and torch.isfinite(C).all()
+    # oracle with the batch-global reference: mel power of the six clips, clip floor from the device's global maximum
+    Sm = ao.melspectrogram(r_want, sr=16000, n_fft=2048, hop_length=512, n_mels=128)
+    gmax = float(ap.melspectrogram(y16, sr=16000, n_fft=2048, hop_length=512, n_mels=128).max())
+    db = 10.0 * np.log10(np.maximum(Sm, 1e-10))
+    db = np.maximum(db, 10.0 * np.log10(max(gmax, 1e-10)) - 80.0)
+    want = ao.mfcc(S=db.astype(np.float32), n_mfcc=13)        # a given S is taken as dB: DCT-II ortho (mfcc.py:253-287)
+    np.testing.assert_allclose(host(C[idx]), want, rtol=1e-4, atol=2e-3)
+    # permutation of the clips permutes the rows (the clip floor is global)
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    Cp = ap.mfcc(y16[perm].contiguous(), sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    assert torch.equal(Cp, C[perm])
+    # gain 4 = +12.04 dB on every bin and on the clip floor alike: only c0 moves, by 20 log10(4) sqrt(128)
+    C4 = ap.mfcc(y16 * 4.0, sr=16000, n_mfcc=13, n_fft=2048, hop_length=512, n_mels=128)
+    shift = 20.0 * np.log10(4.0) * np.sqrt(128.0)
+    np.testing.assert_allclose(host(C4[:8, 0] - C[:8, 0]), shift, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(host(C4[:8, 1:]), host(C[:8, 1:]), rtol=0, atol=5e-3)
