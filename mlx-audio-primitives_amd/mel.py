@@ -124,15 +124,22 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
                    win_length: int | None = None, window="hann", center: bool = True,
                    pad_mode: str = "constant", power: float = 2.0, n_mels: int = 128,
                    fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
-                   norm: str | None = "slaney", _max_key: torch.Tensor | None = None) -> torch.Tensor:
+                   norm: str | None = "slaney") -> torch.Tensor:
     """mel_basis @ |stft(y)|**power (reference mel.py:245-352), fused on the GPU.
 
-    Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32.  ``_max_key`` (internal,
-    mfcc): a 1-element int32 device tensor that receives the order-preserving key of max(out)."""
+    Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32."""
+    return _melspectrogram_max(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, power, n_mels,
+                               fmin, fmax, htk, norm, None)
+
+
+def _melspectrogram_max(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, power, n_mels, fmin, fmax,
+                        htk, norm, max_key):
+    """`melspectrogram` that also leaves the order-preserving key of max(out) in `max_key` (a 1-element int32
+    device tensor, or None): the reference level of mfcc's dB stage, out of the same kernel."""
     def bank(dev):
         return _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
 
-    return _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, _max_key)
+    return _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key)
 
 
 def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key=None):

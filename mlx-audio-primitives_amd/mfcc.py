@@ -59,36 +59,34 @@ def mfcc(y=None, sr: int = 22050, S=None, n_mfcc: int = 20, dct_type: int = 2, n
          lifter: int = 0, n_fft: int = 2048, hop_length: int = 512, win_length: int | None = None,
          window="hann", center: bool = True, pad_mode: str = "constant", power: float = 2.0,
          n_mels: int = 128, fmin: float = 0.0, fmax: float | None = None, htk: bool = False,
-         mel_norm: str | None = "slaney", group=None, _max_reduce=None) -> torch.Tensor:
+         mel_norm: str | None = "slaney") -> torch.Tensor:
     """Mel-frequency cepstral coefficients (reference mfcc.py:143-287).
 
-    Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames).
+    Returns (n_mfcc, n_frames) or (batch, n_mfcc, n_frames).  (A batch sharded by clip over several GPUs:
+    ``sharding.mfcc_sharded``, which all-reduces the 4-byte global maximum the dB stage clips against.)"""
+    return _mfcc_impl(y, sr, S, n_mfcc, dct_type, norm, lifter, n_fft, hop_length, win_length, window, center,
+                      pad_mode, power, n_mels, fmin, fmax, htk, mel_norm, None)
 
-    ``group`` (not in the reference, which is single-device): when the batch is sharded by clip
-    over the ranks of a torch.distributed process group, pass that group (or ``True`` for the
-    default group) and the max(S) that the dB stage clips against (global over the whole batch,
-    convert.py:58) is MAX-all-reduced — 4 bytes — between the mel kernel and the dB + DCT kernel,
-    so every rank produces exactly the rows the unsharded call would.  ``_max_reduce`` is the
-    same hook as a callable on the 1-element int32 key tensor (tests)."""
+
+def _mfcc_impl(y, sr, S, n_mfcc, dct_type, norm, lifter, n_fft, hop_length, win_length, window, center, pad_mode,
+               power, n_mels, fmin, fmax, htk, mel_norm, max_reduce):
+    """`mfcc`; ``max_reduce`` (None, or a callable on the 1-element int32 key tensor of max(S)) runs between the
+    mel kernel and the dB + DCT kernel: the hook a clip-sharded batch needs (convert.py:58 clips against the
+    maximum of the WHOLE batch)."""
     validate_positive(n_mfcc, "n_mfcc")
     provided = S is not None
     max_key = None
     if S is None:
         # the mel kernel also leaves max(S) for the top_db clip of the dB stage (one atomic per wave)
-        from .mel import _is_pcm16, _to_device_pcm16
+        from .mel import _is_pcm16, _melspectrogram_max, _to_device_pcm16
         y = _to_device_pcm16(y) if _is_pcm16(y) else _x.to_device_f32(y)
         max_key = torch.empty(1, dtype=torch.int32, device=y.device)
-        S = melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop_length, win_length=win_length,
-                           window=window, center=center, pad_mode=pad_mode, power=power,
-                           n_mels=n_mels, fmin=fmin, fmax=fmax, htk=htk, norm=mel_norm,
-                           _max_key=max_key)
+        S = _melspectrogram_max(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, power, n_mels,
+                                fmin, fmax, htk, mel_norm, max_key)
         if S.numel() == 0:
             max_key = None
-        elif _max_reduce is not None:
-            _max_reduce(max_key)
-        elif group is not None:
-            from .sharding import global_max_key
-            global_max_key(max_key, None if group is True else group)
+        elif max_reduce is not None:
+            max_reduce(max_key)
     else:
         S = _x.to_device_f32(S)
     batched = S.ndim == 3

@@ -67,7 +67,7 @@ def global_max_key(key: torch.Tensor, group=None) -> torch.Tensor:
     for max(S) (csrc: ap_fkey — keys compare as UNSIGNED 32-bit integers, the tensor holding one
     is int32).  This is the single cross-shard dependency of the path: a clip-sharded
     ``mfcc`` / ``power_to_db(top_db=...)`` clips against the max of the WHOLE batch
-    (convert.py:58).  ``mfcc(..., group=g)`` calls it between the mel kernel and the dB + DCT
+    (convert.py:58).  ``mfcc_sharded`` calls it between the mel kernel and the dB + DCT
     kernel; world_size 1 / no process group is a no-op."""
     import torch.distributed as dist
 
@@ -98,3 +98,24 @@ def _rank_world(rank, world_size):
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
     return rank, world_size
+
+
+def mfcc_sharded(y, group=None, *, _max_reduce=None, **kw) -> torch.Tensor:
+    """`mfcc` of this rank's clips when the batch is sharded by clip over the ranks of `group` (None = the
+    default process group): the max(S) the dB stage clips against (global over the whole batch, convert.py:58)
+    is MAX-all-reduced - 4 bytes - between the mel kernel and the dB + DCT kernel, so every rank produces
+    exactly the rows the unsharded call would.  Keyword arguments are `mfcc`'s; world size 1 / no process group
+    is plain `mfcc`.  ``_max_reduce`` (tests): a callable on the 1-element int32 key tensor instead of the
+    all-reduce."""
+    import inspect
+
+    from . import mfcc as _m
+
+    names = [p for p in inspect.signature(_m.mfcc).parameters][1:]
+    defaults = {n: p.default for n, p in inspect.signature(_m.mfcc).parameters.items()}
+    unknown = set(kw) - set(names)
+    if unknown:
+        raise TypeError(f"mfcc_sharded() got unexpected keyword arguments {sorted(unknown)}")
+    args = [kw.get(n, defaults[n]) for n in names]
+    reduce = _max_reduce if _max_reduce is not None else (lambda key: global_max_key(key, group))
+    return _m._mfcc_impl(y, *args, reduce)

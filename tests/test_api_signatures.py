@@ -1,7 +1,7 @@
 """Drop-in check of the host-side mirror: every function the reference exports exists here with the same
 parameter names, order and literal defaults (tests/golden/api_signatures.json, taken from the reference's
 source text by tests/golden/make_signatures.py).  Extra keyword parameters after the reference's are allowed
-(e.g. mfcc(group=)); nothing here touches a GPU."""
+; nothing here touches a GPU."""
 import importlib
 import inspect
 import json

@@ -25,6 +25,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 import mlx_audio_primitives_amd as ap  # noqa: E402
+from mlx_audio_primitives_amd import sharding  # noqa: E402
 
 
 def dev(x):
@@ -217,13 +218,13 @@ def test_mfcc_clip_sharded_with_reduced_key_equals_unsharded():
     full = ap.mfcc(yd, **kw)
     shards = [yd[:4].contiguous(), yd[4:].contiguous()]
     keys = []
-    local = [ap.mfcc(s, _max_reduce=lambda k: keys.append(k.clone()), **kw) for s in shards]
+    local = [sharding.mfcc_sharded(s, _max_reduce=lambda k: keys.append(k.clone()), **kw) for s in shards]
     assert not torch.equal(torch.cat(local), full)          # per-shard clip floors differ: the hook matters
     wide = torch.stack([k.to(torch.int64) & 0xFFFFFFFF for k in keys]).max().to(torch.int32)
-    fixed = [ap.mfcc(s, _max_reduce=lambda k: k.fill_(wide), **kw) for s in shards]
+    fixed = [sharding.mfcc_sharded(s, _max_reduce=lambda k: k.fill_(wide), **kw) for s in shards]
     assert torch.equal(torch.cat(fixed), full)
-    # world size 1: group=True is a no-op
-    assert torch.equal(ap.mfcc(yd, group=True, **kw), full)
+    # world size 1: the all-reduce is a no-op
+    assert torch.equal(sharding.mfcc_sharded(yd, **kw), full)
     np.testing.assert_allclose(host(full), ao.mfcc(y, **kw), rtol=1e-4, atol=2e-3)
 
 

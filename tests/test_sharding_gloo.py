@@ -144,6 +144,19 @@ def test_bench_launches_its_own_ranks():
     assert rec["value"] > 0 and "stub" in rec["data"]
 
 
+def test_bench_cfg5_workload_and_separate_gather():
+    """BASELINE config 5 as a bench workload (512 clips x 30 s @16 kHz per GPU, Whisper mel parameters): two gloo
+    ranks with the no-op step; the final all-gather of the outputs is timed on its own and never enters `value`."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-step", "--workload", "cfg5")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["config"]["clips_per_gpu"] == 512 and rec["config"]["frames_per_clip"] == 3001
+    assert "n_fft=400 hop=160 n_mels=80" in rec["config"]["workload"]
+    assert rec["gather"]["ms"] > 0 and "not in `value`" in rec["gather"]["note"]
+    assert abs(rec["value"] - 2 * 512 * 3001 * 2 / (rec["ms_per_step"] * 2 * 1e-3)) / rec["value"] < 1e-6
+
+
 def test_bench_launcher_reports_a_failed_rank():
     r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-step", "--stub-fail-rank", "1",
                    timeout=300)

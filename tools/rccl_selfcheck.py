@@ -20,7 +20,7 @@ torch.cuda.synchronize()
 print("max_over_ranks", sharding.max_over_ranks(1.25, device=dev))
 y = torch.randn(4, 22050, device=dev)
 a = ap.mfcc(y, n_mfcc=13)
-b = ap.mfcc(y, n_mfcc=13, group=True)
+b = sharding.mfcc_sharded(y, n_mfcc=13)
 print("mfcc group == local:", bool(torch.equal(a, b)))
 dist.barrier()
 dist.destroy_process_group()
