@@ -197,6 +197,18 @@ int ap_melspec_max_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, 
                        int64_t T, const float *fb /*dev*/, const int32_t *plan /*dev or NULL*/,
                        const int32_t *desc /*host or NULL*/, int n_mels, float power,
                        float *out /*dev*/, uint32_t *max_key_dev /*dev or NULL*/, void *stream);
+/* The same with the rows of `out` `row_stride` floats apart (row_stride >= T: the (B, M, T) result is a strided view of
+ * a (B, M, row_stride) buffer, the columns T..row_stride-1 are never written).  With row_stride a multiple of 8 the
+ * n_fft = 2048 run kernel's 8-frame output runs are whole aligned 32-byte sectors.  Served by that kernel only
+ * (ap_melspec_rows_fused says whether it applies: n_fft = 2048, power 1 or 2, <= 128 filters, constant padding with
+ * an even hop or center = 0); AP_ERR_UNSUPPORTED otherwise.  No reference counterpart: mx.matmul yields dense rows. */
+int ap_melspec_rows_fused(int n_fft, int hop, int center, int pad_mode, int n_mels, float power,
+                          const int32_t *plan /*host or NULL*/, const int32_t *desc /*host*/);
+int ap_melspec_rows_f32(const float *y /*dev*/, int64_t B, int64_t L, int n_fft, int hop,
+                        const float *window /*dev*/, const float *tw /*dev*/, int center, int pad_mode,
+                        int64_t T, int64_t row_stride, const float *fb /*dev*/, const int32_t *plan /*dev*/,
+                        const int32_t *desc /*host*/, int n_mels, float power, float *out /*dev (B,M,row_stride)*/,
+                        uint32_t *max_key_dev /*dev or NULL*/, void *stream);
 
 /* irfft of every frame: S (B,F,T) complex64 -> frames (B,T,n_fft) float32,
  * 1/n_fft scaled; imaginary parts of the DC and Nyquist bins are ignored —

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ap_mel_filterbank_host", "ap_dct_matrix_host", "ap_twiddle_table_host", "ap_fft_supported",
     "ap_mel_plan_words", "ap_mel_plan_host",
     "ap_pad_f32", "ap_frame_f32", "ap_overlap_add_f32",
-    "ap_stft_f32", "ap_stft_rows_f32", "ap_melspec_f32", "ap_melspec_max_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_rows_f32", "ap_istft_workspace_floats",
+    "ap_stft_f32", "ap_stft_rows_f32", "ap_melspec_f32", "ap_melspec_max_f32", "ap_melspec_rows_fused", "ap_melspec_rows_f32", "ap_irfft_frames_f32", "ap_istft_f32", "ap_istft_rows_f32", "ap_istft_workspace_floats",
     "ap_magnitude_f32", "ap_phase_f32", "ap_complex_unary_rows_f32",
     "ap_resample_poly_ntaps", "ap_resample_poly_taps_host", "ap_resample_poly_f32",
     "ap_extend_f32", "ap_resample_poly_pad_samples", "ap_resample_poly_padded_f32", "ap_resample_fft_chirp_f32",
@@ -83,6 +83,8 @@ def _declare(lib) -> None:
         "ap_stft_rows_f32": [P, L, L, I, I, P, P, I, I, L, L, P, P],
         "ap_melspec_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P],
         "ap_melspec_max_f32": [P, L, L, I, I, P, P, I, I, L, P, P, P, I, F, P, P, P],
+        "ap_melspec_rows_fused": [I, I, I, I, I, F, P, P],
+        "ap_melspec_rows_f32": [P, L, L, I, I, P, P, I, I, L, L, P, P, P, I, F, P, P, P],
         "ap_mel_plan_host": [P, I, I, P, P],
         "ap_irfft_frames_f32": [P, L, L, I, P, P, P],
         "ap_istft_f32": [P, L, L, I, I, P, P, P, L, L, P, P],

@@ -274,6 +274,7 @@ static inline int ap_prepare_mel_run(ApMelWaveParams &W, const ApStftParams &P, 
     W.max_key = nullptr;
     W.L = P.L;
     W.T = P.T;
+    W.Ts = P.T;                                            // dense rows; ap_melspec_rows_f32 overwrites it
     W.tiles_per_clip = 0;
     W.n_tiles = 0;
     W.n_clips = B;
@@ -692,8 +693,9 @@ static inline int ap_prepare_istft16(ApIstft16Params &W, const float *S, const f
     W.off_carry = off; off += 2 * (2048 - hop) * (int)sizeof(float);
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;
-    // persistent, one workgroup per CU; a stretch that starts inside a clip re-runs 8 frames, so >= 2 groups each
-    int64_t g = W.n_g16 / 2;
+    // persistent, one workgroup per CU; a stretch that starts inside a clip re-runs 8 frames, so >= 4 steps (of 8
+    // frames) each
+    int64_t g = ((T + APS_WAVES - 1) / APS_WAVES) * B / 4;
     if (g > 256) g = 256;
     if (g < 1) g = 1;
     *grid = (int)g;

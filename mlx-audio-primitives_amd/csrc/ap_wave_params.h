@@ -23,6 +23,7 @@ struct ApMelWaveParams {
     float *out;                // (B, M, T)
     unsigned *max_key;         // NULL, or the order-preserving key of max(out) to raise (one atomic per wave)
     int64_t L, T, tiles_per_clip, n_tiles, n_clips;
+    int64_t Ts;                // run kernel: floats between the rows of `out` (T = dense; a multiple of 8 = whole sectors)
     int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots;   // n_slots: partial sums per frame
     int hopj;                  // hop / 128 when the next frame reuses this one's registers (2, 4, 8), else 0
     int max_row_parts;         // largest number of parts of one row

@@ -3,6 +3,7 @@
 // memory or synchronises.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <mutex>
 
 #include <cstdio>
 #include <cstring>
@@ -343,6 +344,25 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
                        const float *tw, int center, int pad_mode, int64_t T, const float *fb,
                        const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,
                        uint32_t *max_key_dev, void *stream) {
+    return ap_melspec_rows_f32(y, B, L, n_fft, hop, window, tw, center, pad_mode, T, T, fb, plan, desc, n_mels, power, out,
+                               max_key_dev, stream);
+}
+
+int ap_melspec_rows_fused(int n_fft, int hop, int center, int pad_mode, int n_mels, float power, const int32_t *plan,
+                          const int32_t *desc) {
+    static const bool force_wave = std::getenv("AP_MEL2048_WAVE") != nullptr;
+    if (force_wave || n_fft != 2048 || !(power == 2.0f || power == 1.0f) || !ap_mel_wave_eligible(n_fft, plan, desc)) return 0;
+    (void)hop; (void)center; (void)pad_mode;              // every padding mode has a run-kernel instantiation
+    return (n_mels <= 128 && desc && desc[12] <= 256 && desc[15] <= 4) ? 1 : 0;
+}
+
+int ap_melspec_rows_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
+                        const float *tw, int center, int pad_mode, int64_t T, int64_t row_stride, const float *fb,
+                        const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,
+                        uint32_t *max_key_dev, void *stream) {
+    if (row_stride < T) AP_FAIL(AP_ERR_INVALID, "melspectrogram: row_stride (%lld) must be >= the number of frames (%lld)",
+                                (long long)row_stride, (long long)T);
+    const bool rows = row_stride != T;
     ApStftParams P;
     int rc = ap_prepare_stft(P, y, B, L, n_fft, hop, window, tw, center, pad_mode, T);
     if (rc != AP_OK) return rc;
@@ -356,6 +376,7 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
         static const bool force_wave = std::getenv("AP_MEL2048_WAVE") != nullptr;
         if (!force_wave && (power == 2.0f || power == 1.0f) &&
             ap_prepare_mel_run(W, P, B, plan, desc, APM_WAVES, APW_X_COMPLEX, APM_PARTIAL_OFF, &n_pass, &grid) == AP_OK) {
+            W.Ts = row_stride;
             if (max_key_dev) {
                 hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
                 if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
@@ -367,6 +388,7 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
             return power == 2.0f ? ap_launch_mel_run<2>(W, n_pass, grid, stream)
                                  : ap_launch_mel_run<1>(W, n_pass, grid, stream);
         }
+        if (rows) AP_FAIL(AP_ERR_UNSUPPORTED, "melspectrogram: padded rows are served by the n_fft = 2048 run kernel only");
         if (ap_prepare_mel_wave(W, P, B, plan, desc, &grid) == AP_OK) {
             if (max_key_dev) {            // the kernel raises the key itself: one atomic per wave
                 hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
@@ -379,6 +401,7 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
             return ap_launch_mel_wave_p<1>(W, grid, power, stream);
         }
     }
+    if (rows) AP_FAIL(AP_ERR_UNSUPPORTED, "melspectrogram: padded rows are served by the n_fft = 2048 run kernel only");
     if (n_fft == 400 || n_fft == 512 || n_fft == 256) {     // eight frames per wave (kernels_frames8.h)
         static const bool force_ct = std::getenv("AP_MEL400_CT") != nullptr;     // A/B switch: keep the LDS engine
         if (!force_ct) {
@@ -710,31 +733,26 @@ int ap_griffinlim_f32(const float *S, const float *angles, int64_t B, int64_t T,
 // Griffin-Lim with line-padded workspaces (n_fft = 2048, TR == T): every spectrum of the loop lives with its rows
 // `row_stride` complex values apart, so the STFT writes and the ISTFT reads whole 128-byte lines
 // (kernels_stft16.h ALIGNED = 1, kernels_istft16.h) and the projection moves 16 bytes per lane.
-int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64_t T, int64_t row_stride, int n_fft,
-                           int hop, const float *window, const float *tw, int center, int pad_mode, int64_t out_offset,
-                           int64_t y_len, int n_iter, float momentum, float *rebuilt, float *tprev, float *R, float *y,
-                           void *stream) {
-    if (!S || !angles || !rebuilt || !tprev || !R || !y || !window || !tw) AP_FAIL(AP_ERR_INVALID, "griffinlim: NULL buffer");
-    if (n_iter <= 0) AP_FAIL(AP_ERR_INVALID, "n_iter must be positive, got %d", n_iter);
-    if (momentum < 0.0f || momentum >= 1.0f) AP_FAIL(AP_ERR_INVALID, "momentum must be in [0, 1)");
-    if (n_fft != 2048 || row_stride < T || (row_stride & 1) || row_stride > (1 << 20) ||
-        ((reinterpret_cast<uintptr_t>(rebuilt) | reinterpret_cast<uintptr_t>(tprev) | reinterpret_cast<uintptr_t>(R)) & 15))
-        AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: padded rows need n_fft = 2048, an even row_stride >= T and 16-byte aligned workspaces");
-    if (!ap_istft_fused_shape(B, T, 2048, hop, out_offset)) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: shape not served with padded rows");
+//
+// One chain (init projection, n_iter x {istft, stft, projection}, final istft) over clips [0, B) on ONE stream:
+static int ap_gl_rows_chain(const float *S, const float *angles, int64_t B, int64_t T, int64_t row_stride, int hop,
+                            const float *window, const float *tw, int center, int pad_mode, int64_t out_offset,
+                            int64_t y_len, int n_iter, float momentum, float *rebuilt, float *tprev, float *R, float *y,
+                            bool fused_projection, hipStream_t stream) {
     ApStftParams P;
-    int rc = ap_prepare_stft(P, y, B, y_len, n_fft, hop, window, tw, center, pad_mode, T);   // also checks TR == T
+    int rc = ap_prepare_stft(P, y, B, y_len, 2048, hop, window, tw, center, pad_mode, T);   // also checks TR == T
     if (rc != AP_OK) return rc;
     const int64_t rows = B * 1025;
     const int64_t pairs = rows * (row_stride / 2);
     const int grid = ap_grid_1d(pairs, AP_BLOCK, kApStreamGrid);
     auto project = [&](const float *ang, const float *cur, const float *prev, float *tp) {
         if (pairs < (int64_t(1) << 31))
-            hipLaunchKernelGGL(ap_gl_rows_kernel<int>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, S, ang,
+            hipLaunchKernelGGL(ap_gl_rows_kernel<int>, dim3(grid), dim3(AP_BLOCK), 0, stream, S, ang,
                                reinterpret_cast<const ap_float2 *>(cur), reinterpret_cast<const ap_float2 *>(prev), rows,
                                (int)T, (int)row_stride, momentum, reinterpret_cast<ap_float2 *>(tp),
                                reinterpret_cast<ap_float2 *>(rebuilt));
         else
-            hipLaunchKernelGGL(ap_gl_rows_kernel<int64_t>, dim3(grid), dim3(AP_BLOCK), 0, (hipStream_t)stream, S, ang,
+            hipLaunchKernelGGL(ap_gl_rows_kernel<int64_t>, dim3(grid), dim3(AP_BLOCK), 0, stream, S, ang,
                                reinterpret_cast<const ap_float2 *>(cur), reinterpret_cast<const ap_float2 *>(prev), rows,
                                (int)T, (int)row_stride, momentum, reinterpret_cast<ap_float2 *>(tp),
                                reinterpret_cast<ap_float2 *>(rebuilt));
@@ -751,10 +769,7 @@ int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64
         if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: istft shape not served with padded rows");
         if (rc != AP_OK) return rc;
         P.out_c = reinterpret_cast<ap_float2 *>(cur);
-        // the projection rides in the STFT's store phase (kernels_stft16.h, GL = 1) when the rows are whole lines;
-        // AP_GL_PROJECT_PASS=1 keeps the separate pass for A/B measurements
-        static const bool separate = std::getenv("AP_GL_PROJECT_PASS") != nullptr;
-        rc = separate ? 1 : ap_launch_stft16_gl(P, B, row_stride, prev, S, momentum, rebuilt, stream);
+        rc = fused_projection ? ap_launch_stft16_gl(P, B, row_stride, prev, S, momentum, rebuilt, stream) : 1;
         if (rc == 1) {
             rc = ap_launch_stft16(P, B, row_stride, stream);
             if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: stft shape not served with padded rows");
@@ -765,6 +780,75 @@ int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64
     }
     rc = ap_launch_istft16(rebuilt, tw, B, T, row_stride, window, hop, out_offset, y_len, y, stream);
     if (rc == 1) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: istft shape not served with padded rows");
+    return rc;
+}
+
+// Helper streams of the Griffin-Lim loop, one set per device, created on first use and kept for the life of the
+// process (the only state this library holds).  Clips are independent, so the batch runs as AP_GL_STREAMS
+// (default 2) chains of half the clips each: the three kernels of an iteration are small at Griffin-Lim sizes
+// (45-80 us each at 64 x 5 s), each alternates compute phases with bursts of memory traffic, and the streaming
+// projection pass needs neither LDS nor many registers - side by side, one chain's kernels fill the other's
+// bubbles.  The caller's stream forks into the helpers and joins them again with events: no host
+// synchronisation, and everything stays ordered with respect to the caller's stream.
+struct ApGlStreams {
+    hipStream_t s[4];
+    hipEvent_t fork, join[4];
+    bool ok;
+};
+static ApGlStreams *ap_gl_streams() {
+    static ApGlStreams per_device[64];
+    static bool made[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    ApGlStreams &g = per_device[dev];
+    if (!made[dev]) {
+        made[dev] = true;
+        g.ok = hipEventCreateWithFlags(&g.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && g.ok; ++i)
+            g.ok = hipStreamCreateWithFlags(&g.s[i], hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&g.join[i], hipEventDisableTiming) == hipSuccess;
+    }
+    return g.ok ? &g : nullptr;
+}
+
+int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64_t T, int64_t row_stride, int n_fft,
+                           int hop, const float *window, const float *tw, int center, int pad_mode, int64_t out_offset,
+                           int64_t y_len, int n_iter, float momentum, float *rebuilt, float *tprev, float *R, float *y,
+                           void *stream) {
+    if (!S || !angles || !rebuilt || !tprev || !R || !y || !window || !tw) AP_FAIL(AP_ERR_INVALID, "griffinlim: NULL buffer");
+    if (n_iter <= 0) AP_FAIL(AP_ERR_INVALID, "n_iter must be positive, got %d", n_iter);
+    if (momentum < 0.0f || momentum >= 1.0f) AP_FAIL(AP_ERR_INVALID, "momentum must be in [0, 1)");
+    if (n_fft != 2048 || row_stride < T || (row_stride & 1) || row_stride > (1 << 20) ||
+        ((reinterpret_cast<uintptr_t>(rebuilt) | reinterpret_cast<uintptr_t>(tprev) | reinterpret_cast<uintptr_t>(R)) & 15))
+        AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: padded rows need n_fft = 2048, an even row_stride >= T and 16-byte aligned workspaces");
+    // A/B switches: AP_GL_STREAMS=1 keeps the whole batch on the caller's stream; AP_GL_FUSED_PROJECTION=1 lets the
+    // projection ride in the STFT's store phase (kernels_stft16.h GL = 1: measured equal to the separate pass)
+    static const int n_streams_env = std::getenv("AP_GL_STREAMS") ? std::atoi(std::getenv("AP_GL_STREAMS")) : 2;
+    static const bool fused = std::getenv("AP_GL_FUSED_PROJECTION") != nullptr;
+    int n_sub = n_streams_env < 1 ? 1 : (n_streams_env > 4 ? 4 : n_streams_env);
+    while (n_sub > 1 && !ap_istft_fused_shape(B / n_sub, T, 2048, hop, out_offset)) --n_sub;
+    if (!ap_istft_fused_shape(B / n_sub, T, 2048, hop, out_offset)) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: shape not served with padded rows");
+    ApGlStreams *gs = n_sub > 1 ? ap_gl_streams() : nullptr;
+    if (!gs) n_sub = 1;
+    if (n_sub == 1)
+        return ap_gl_rows_chain(S, angles, B, T, row_stride, hop, window, tw, center, pad_mode, out_offset, y_len, n_iter,
+                                momentum, rebuilt, tprev, R, y, fused, (hipStream_t)stream);
+    if (hipEventRecord(gs->fork, (hipStream_t)stream) != hipSuccess) AP_FAIL(AP_ERR_HIP, "griffinlim: hipEventRecord failed");
+    int rc = AP_OK;
+    const int64_t spec = 1025 * T, wsp = 1025 * row_stride * 2;
+    for (int i = 0; i < n_sub; ++i) {
+        const int64_t b0 = B * i / n_sub, b1 = B * (i + 1) / n_sub;
+        if (hipStreamWaitEvent(gs->s[i], gs->fork, 0) != hipSuccess) AP_FAIL(AP_ERR_HIP, "griffinlim: hipStreamWaitEvent failed");
+        const int rci = ap_gl_rows_chain(S + b0 * spec, angles + b0 * spec, b1 - b0, T, row_stride, hop, window, tw, center,
+                                         pad_mode, out_offset, y_len, n_iter, momentum, rebuilt + b0 * wsp, tprev + b0 * wsp,
+                                         R + b0 * wsp, y + b0 * y_len, fused, gs->s[i]);
+        if (rci != AP_OK && rc == AP_OK) rc = rci;
+        // join even after an error: the caller's stream must not run ahead of what was enqueued
+        if (hipEventRecord(gs->join[i], gs->s[i]) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, gs->join[i], 0) != hipSuccess)
+            AP_FAIL(AP_ERR_HIP, "griffinlim: joining the helper streams failed");
+    }
     return rc;
 }
 

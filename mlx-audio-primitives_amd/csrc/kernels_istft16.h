@@ -23,32 +23,21 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     const ap_float2 *TW2 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw2);
     const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
     ap_float2 *IB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ib);        // [2][129][17]
-    {
-        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
-        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
-        if (tid < 64)       // signs of the quad stage folded in, as in apw_fill_tables
-            tw2[(tid >> 4) * 17 + (tid & 15)] = ap_scale(P.tw[32 * (tid >> 4) * (tid & 15)], ((tid >> 4) == 1 || (tid >> 4) == 2) ? -1.0f : 1.0f);
-        for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
-        float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
-        for (int i = tid; i < 2 * APW_NC; i += 64 * APS_WAVES) win[i] = P.window[i];
-        // 1 / max(sum of w^2 over the n_fft / hop frames that cover a position, 1e-8) by phase: inside a clip
-        // (every covering frame exists) the divisor of overlap_add.metal:44-52 only depends on the position mod hop
-        float *inv = reinterpret_cast<float *>(ap_smem + P.off_inv);
-        for (int p = tid; p < P.hop; p += 64 * APS_WAVES) {
-            float w2 = 0.0f;
-            for (int q = p; q < 2 * APW_NC; q += P.hop) w2 += P.window[q] * P.window[q];   // increasing frame order = decreasing q
-            inv[p] = 1.0f / fmaxf(w2, 1e-8f);
-        }
-    }
-    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
-    AP_LDS_BARRIER();
     const int F = APW_NC + 1;
-    const float scale = 1.0f / 1024.0f;    // 1/n_fft, and the merge below works at half scale
     const int Ti = (int)P.T, Ts = (int)P.Ts;
-
-    const int64_t g_lo = P.n_g16 * (int64_t)blockIdx.x / gridDim.x;
-    const int64_t g_hi = P.n_g16 * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    if (g_lo >= g_hi) return;
+    // A workgroup owns a contiguous stretch of the (clip, 8-frame step) stream, [h_lo, h_hi): the loads come in
+    // 16-frame groups (two steps), so a stretch may begin with the second step of a group (the first one is then
+    // its store-less warm-up, from the same loads) or end with the first.  Steps rather than groups as the unit
+    // keep the stretches of a small problem even (64 clips x 216 frames on 256 workgroups: 6.75 steps each).
+    const int64_t hpc = (P.T + APS_WAVES - 1) / APS_WAVES;                       // steps per clip
+    const int64_t n_h = hpc * (P.n_g16 / P.g16_per_clip);
+    const int64_t h_lo = n_h * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t h_hi = n_h * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (h_lo >= h_hi) return;
+    // step h -> its 16-frame group (flattened over clips like P.n_g16) and its half
+    auto group_of = [&](int64_t h) { const int64_t b = h / hpc; return b * P.g16_per_clip + ((h - b * hpc) >> 1); };
+    const int64_t b_lo = h_lo / hpc;
+    const int hc_lo = (int)(h_lo - b_lo * hpc);                                  // first step's index in its clip
     // loader role: thread (sq = tid / 16, sf = tid % 16) fetches frame t0 + sf of the rows sq, 32 + sq (bins
     // 64 c + l) and 64 + sq, 96 + sq (bins 1024 - 64 c - l) of every chunk c, + bin 512 by the first 16 threads
     const int sq0 = tid >> 4, sf0 = tid & 15;
@@ -75,6 +64,35 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
 #pragma unroll
         for (int c = 0; c < 8; ++c) load_chunk(g16, c);
     };
+    // the stretch's first loads go out before the tables are built: they land under the set-up
+    // an even first step inside a clip is preceded by the second step of the group before it (other loads); an odd
+    // one by the first step of its own group
+    const bool warm_prev_group = hc_lo > 0 && !(hc_lo & 1);
+    load16(warm_prev_group ? group_of(h_lo) - 1 : group_of(h_lo));
+    {
+        ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
+        ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
+        if (tid < 64)       // signs of the quad stage folded in, as in apw_fill_tables
+            tw2[(tid >> 4) * 17 + (tid & 15)] = ap_scale(P.tw[32 * (tid >> 4) * (tid & 15)], ((tid >> 4) == 1 || (tid >> 4) == 2) ? -1.0f : 1.0f);
+        for (int i = tid; i < 16 * 64; i += 64 * APS_WAVES) tw1[i] = P.tw[2 * (i & 63) * (i >> 6)];
+        float *win = reinterpret_cast<float *>(ap_smem + P.off_win);
+        for (int i = tid; i < 2 * APW_NC; i += 64 * APS_WAVES) win[i] = P.window[i];
+    }
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    AP_LDS_BARRIER();
+    {
+        // 1 / max(sum of w^2 over the n_fft / hop frames that cover a position, 1e-8) by phase: inside a clip
+        // (every covering frame exists) the divisor of overlap_add.metal:44-52 only depends on the position mod hop
+        // (from the LDS copy of the window; visible to the gathers after the staging pass's barriers)
+        const float *win = reinterpret_cast<const float *>(ap_smem + P.off_win);
+        float *inv = reinterpret_cast<float *>(ap_smem + P.off_inv);
+        for (int p = tid; p < P.hop; p += 64 * APS_WAVES) {
+            float w2 = 0.0f;
+            for (int q = p; q < 2 * APW_NC; q += P.hop) w2 += win[q] * win[q];
+            inv[p] = 1.0f / fmaxf(w2, 1e-8f);
+        }
+    }
+    const float scale = 1.0f / 1024.0f;    // 1/n_fft, and the merge below works at half scale
     // pre -> LDS -> every wave's bins of its two frames: xk[r] = S[64 r + lane], xm[r] = S[1024 - 64 r - lane]
     // `next16 >= 0`: as soon as chunk c has left its registers, the loads of chunk c of that group are issued
     // into them: they have a whole period (two transforms and two gathers) to land, and the bursts of the 256
@@ -235,22 +253,26 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     ap_float2 xkA[8], xmA[8], xhA, xkB[8], xmB[8], xhB;
     // A stretch that starts inside a clip first re-runs the 8 frames before it with the stores disabled: they
     // rebuild the carry (its length 2048 - hop is at most 7 frames for hop >= 256).
-    if (g_lo % P.g16_per_clip != 0) {
-        load16(g_lo - 1);
-        stage(xkA, xmA, xhA, xkB, xmB, xhB, g_lo);
-        const int64_t b = (g_lo - 1) / P.g16_per_clip;
-        const int t0 = (int)((g_lo - 1 - b * P.g16_per_clip) * APS16_G);
+    if (warm_prev_group) {
+        const int64_t gp = group_of(h_lo) - 1;
+        stage(xkA, xmA, xhA, xkB, xmB, xhB, group_of(h_lo));
+        const int64_t b = gp / P.g16_per_clip;
+        const int t0 = (int)((gp - b * P.g16_per_clip) * APS16_G);
         step(xkB, xmB, xhB, b, t0 + 8, 1, false);
-    } else {
-        load16(g_lo);
     }
-    for (int64_t g16 = g_lo; g16 < g_hi; ++g16) {
-        const int64_t b = g16 / P.g16_per_clip;
-        const int t0 = (int)((g16 - b * P.g16_per_clip) * APS16_G);
-        stage(xkA, xmA, xhA, xkB, xmB, xhB, g16 + 1 < g_hi ? g16 + 1 : -1);
-        step(xkA, xmA, xhA, b, t0, 0, true);
-        // the second step only exists when the clip has frames there; its carry parity continues either way
-        // (a clip that ends after the first step starts the next one with a zeroed carry_in of parity 0)
-        if (t0 + 8 < Ti) step(xkB, xmB, xhB, b, t0 + 8, 1, true);
+    for (int64_t h = h_lo; h < h_hi;) {
+        const int64_t b = h / hpc;
+        const int hc = (int)(h - b * hpc);
+        const int t0 = (hc >> 1) * APS16_G;
+        const bool startB = hc & 1;                                  // only the stretch's first step can be odd
+        const bool haveB = t0 + 8 < Ti;                              // the clip has frames in the group's second half
+        const bool ownB = haveB && (startB || h + 1 < h_hi);
+        const int64_t h_next = h + (startB ? 1 : (haveB ? 2 : 1));    // first step of the next group
+        stage(xkA, xmA, xhA, xkB, xmB, xhB, h_next < h_hi ? group_of(h_next) : -1);
+        step(xkA, xmA, xhA, b, t0, 0, !startB);                      // startB: the warm-up of the step this stretch starts with
+        // (the carry parity continues either way: a clip that ends after a first step starts the next one with a
+        //  zeroed carry_in of parity 0)
+        if (ownB) step(xkB, xmB, xhB, b, t0 + 8, 1, true);
+        h = h_next;
     }
 }

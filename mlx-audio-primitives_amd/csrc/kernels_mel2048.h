@@ -255,14 +255,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
                 raw[(j + HOPJ * ROT) & 15] = ld2(b, base, p);
             }
         };
-        load_frame(t, std::integral_constant<int, 0>());
+        // U = 4: the stretch's first frame takes the register rotation r0 = t mod 4 and the run half (t / 4) mod 2, so
+        // that frame t sits at position t mod 8 of the run registers: full runs are then the clip's frames 8 k .. 8 k + 7
+        // and leave as ALIGNED 32-byte pieces of their rows (rows `Ts` floats apart; with Ts a multiple of 8 the
+        // pieces are whole sectors - the output's write amplification was 1.9 x with runs that started wherever the
+        // stretch did).  A clip that ends inside the stretch breaks the alignment for the rest of it.
+        const int r0 = U == 4 ? (t & 3) : 0;
+        if (r0 == 1) load_frame(t, std::integral_constant<int, 1 % U>());
+        else if (r0 == 2) load_frame(t, std::integral_constant<int, 2 % U>());
+        else if (r0 == 3) load_frame(t, std::integral_constant<int, 3 % U>());
+        else load_frame(t, std::integral_constant<int, 0>());
         // The run of finished frames (rows lane and lane + 64) waits in registers for a 32-byte store:
         // position p8 = 4 h + rot of an 8-frame cycle (U = 4: static register, uniform half h), or a
         // shift register (U = 1).
         float acc0[APM_RUN], acc1[APM_RUN];
 #pragma unroll
         for (int i = 0; i < APM_RUN; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-        int nrun = 0, half = 0;
+        int nrun = 0, half = U == 4 ? ((t >> 2) & 1) : 0;
         int64_t f = f_lo;
 
         // one frame; returns false after the last frame of the stretch
@@ -376,12 +385,12 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
             if ((U == 1 ? nrun == APM_RUN : pos == APM_RUN - 1) || clip_ends || !more) {
                 // frame t - nrun + 1 + g sits in register pos - nrun + 1 + g
                 const int first = pos - nrun + 1;
-                float *ob = P.out + b * (int64_t)M * P.T + (t - nrun + 1);
+                float *ob = P.out + b * (int64_t)M * P.Ts + (t - nrun + 1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = lane + 64 * i;
                     if (row < M) {
-                        float *dst = ob + (int64_t)row * P.T;
+                        float *dst = ob + (int64_t)row * P.Ts;
                         const float *src = i == 0 ? acc0 : acc1;
                         if (nrun == APM_RUN) {      // 32 contiguous bytes: two 16-byte stores (4-byte aligned)
                             ap_rsp_f4u lo, hi;
@@ -405,11 +414,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) ap_mel2048_run_kernel(ApMelWa
         if (U == 1) {
             while (frame(std::integral_constant<int, 0>())) {}
         } else {
+            int skip = r0;                        // the first trip enters at rotation r0 (uniform branches)
             for (;;) {
-                if (!frame(std::integral_constant<int, 0>())) break;
-                if (!frame(std::integral_constant<int, 1 % U>())) break;
-                if (!frame(std::integral_constant<int, 2 % U>())) break;
+                if (skip <= 0 && !frame(std::integral_constant<int, 0>())) break;
+                if (skip <= 1 && !frame(std::integral_constant<int, 1 % U>())) break;
+                if (skip <= 2 && !frame(std::integral_constant<int, 2 % U>())) break;
                 if (!frame(std::integral_constant<int, 3 % U>())) break;
+                skip = 0;
                 half ^= 1;
             }
         }

@@ -51,30 +51,6 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
     const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);
     ap_float2 *OB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);        // [2][129][17]
-    apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
-                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
-                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid,
-                    64 * APS_WAVES);
-    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
-    AP_LDS_BARRIER();
-
-#ifndef AP_HOST_EMU
-    // Every workgroup alternates a compute phase (two transforms) with a burst of 131 KB of stores, all 256 of
-    // them with the same period: started together they also burst together, the memory system idles during the
-    // transforms and the stores queue up behind each other during the bursts.  A start-up delay of a quarter
-    // period per workgroup class spreads the bursts over the period.
-    for (int d = (int)((blockIdx.x >> 3) & 3) * P.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
-#endif
-    const int F = APW_NC + 1;
-    const int sq0 = tid >> 4, sf0 = tid & 15;                                // store role of this thread
-    const int Ts = (int)P.Ts, Ts15 = (int)(P.Ts & 15);
-    ap_float2 carry[8][4], carry_mid = ap_mk(0.0f, 0.0f);
-    if (!ALIGNED) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) carry[c][i] = ap_mk(0.0f, 0.0f);
-    }
     ap_float2 raw[16];
     // frame t0 + wave + 8 * second of the group
     auto load_frame = [&](int64_t group, int second) {
@@ -100,6 +76,33 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             }
         }
     };
+    const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
+    const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    if (!PADGEN && g_lo < g_hi) load_frame(g_lo, 0);        // the first frame's samples land under the table set-up
+    apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
+                    reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid,
+                    64 * APS_WAVES);
+    const ApwLane lc = apw_lane_init(lane, TW2, P.tw);
+    AP_LDS_BARRIER();
+
+#ifndef AP_HOST_EMU
+    // Every workgroup alternates a compute phase (two transforms) with a burst of 131 KB of stores, all 256 of
+    // them with the same period: started together they also burst together, the memory system idles during the
+    // transforms and the stores queue up behind each other during the bursts.  A start-up delay of a quarter
+    // period per workgroup class spreads the bursts over the period.
+    for (int d = (int)((blockIdx.x >> 3) & 3) * P.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
+#endif
+    const int F = APW_NC + 1;
+    const int sq0 = tid >> 4, sf0 = tid & 15;                                // store role of this thread
+    const int Ts = (int)P.Ts, Ts15 = (int)(P.Ts & 15);
+    ap_float2 carry[8][4], carry_mid = ap_mk(0.0f, 0.0f);
+    if (!ALIGNED) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) carry[c][i] = ap_mk(0.0f, 0.0f);
+    }
     // windowed frame in raw[] -> xk[r] = X[lane + 64 r], xm[r] = X[1024 - lane - 64 r], zh = Z[512]
     auto transform = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 &zh, int64_t next_group, int next_second) {
         ap_float2 v[16];
@@ -131,9 +134,6 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     // every workgroup owns a contiguous stretch of the (clip, 16-frame group) stream: a row's
     // window is completed one group later by the same thread (ALIGNED = 0), and the lines of
     // consecutive groups follow each other from the same CU
-    const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
-    const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
-    if (!PADGEN && g_lo < g_hi) load_frame(g_lo, 0);
 
     for (int64_t group = g_lo; group < g_hi; ++group) {
         const int64_t b = group / P.groups_per_clip;

@@ -129,20 +129,23 @@ def melspectrogram(y, sr: int = 22050, n_fft: int = 2048, hop_length: int | None
 
     Returns (n_mels, n_frames) or (batch, n_mels, n_frames) float32."""
     return _melspectrogram_max(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, power, n_mels,
-                               fmin, fmax, htk, norm, None)
+                               fmin, fmax, htk, norm, None, lines=True)
 
 
 def _melspectrogram_max(y, sr, n_fft, hop_length, win_length, window, center, pad_mode, power, n_mels, fmin, fmax,
-                        htk, norm, max_key):
+                        htk, norm, max_key, lines=False):
     """`melspectrogram` that also leaves the order-preserving key of max(out) in `max_key` (a 1-element int32
-    device tensor, or None): the reference level of mfcc's dB stage, out of the same kernel."""
+    device tensor, or None): the reference level of mfcc's dB stage, out of the same kernel.  `lines`: the
+    result may be a view with padded rows (see stft._SPECTRUM_LAYOUT); internal callers that hand the array
+    to a kernel that expects dense rows leave it off."""
     def bank(dev):
         return _mel_filterbank_full(sr, n_fft, n_mels, fmin, fmax, htk, norm, dev)
 
-    return _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key)
+    return _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key, lines)
 
 
-def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key=None):
+def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode, power, bank, max_key=None,
+                      lines=False):
     """bank(dev) -> (dense filterbank (M, F), contraction plan, plan descriptor) on `dev`;
     returns bank @ |stft(y)|**power from ONE fused kernel launch."""
     hop_length, win_length = _resolve_stft_args(n_fft, hop_length, win_length)
@@ -159,11 +162,31 @@ def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode
     T = _frame_count(L, n_fft, hop_length, center, pad_mode)
     fb, plan, desc = bank(dev)
     n_rows = fb.shape[0]
-    out = torch.empty((B, n_rows, T), dtype=torch.float32, device=dev)
+    # n_fft = 2048 run kernel: rows padded to a multiple of 8 frames make every 8-frame output run a whole aligned
+    # 32-byte sector (stft._SPECTRUM_LAYOUT: the result is then a strided view with the dense layout's values)
+    from .stft import _spectrum_layout
+    Ts = T
+    if lines and not pcm16 and _spectrum_layout() == "lines" and T % 8 and B * T >= 512 and \
+            _x.lib().ap_melspec_rows_fused(int(n_fft), hop_length, int(bool(center)), _x.PAD_MODES[pad_mode],
+                                          int(n_rows), float(power), _x.ptr(plan), desc.ctypes.data):
+        Ts = -(-T // 8) * 8
+    out = torch.empty((B, n_rows, Ts), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:
         tw = _get_twiddles(n_fft, dev)
         key_ptr = None if max_key is None else max_key.data_ptr()
-        if pcm16:
+        if Ts != T:
+            rc = _x.dlib(dev).ap_melspec_rows_f32(
+                _x.ptr(y), B, L, int(n_fft), hop_length, _x.ptr(win), _x.ptr(tw), int(bool(center)),
+                _x.PAD_MODES[pad_mode], T, Ts, _x.ptr(fb), _x.ptr(plan), desc.ctypes.data, int(n_rows),
+                float(power), _x.ptr(out), key_ptr, _x.stream_ptr(dev))
+            if rc == _x.AP_ERR_UNSUPPORTED:          # a shape the run kernel turns down after all: dense rows
+                Ts = T
+                out = torch.empty((B, n_rows, T), dtype=torch.float32, device=dev)
+            else:
+                _x.check(rc)
+        if Ts != T:
+            pass
+        elif pcm16:
             # 16-bit PCM: converted inside the n_fft=2048 run kernel's loads where
             # that kernel applies, else by one conversion pass into a float32 scratch copy
             fused = _x.lib().ap_melspec_pcm16_fused(L, int(n_fft), hop_length, int(bool(center)),
@@ -183,6 +206,8 @@ def _bank_spectrogram(y, n_fft, hop_length, win_length, window, center, pad_mode
                 float(power), _x.ptr(out), key_ptr, _x.stream_ptr(dev)))
     else:
         out.zero_()
+    if Ts != T:
+        out = out[:, :, :T]
     return out[0] if one_d else out
 
 

@@ -107,9 +107,10 @@ def mfcc_sharded(y, group=None, *, _max_reduce=None, **kw) -> torch.Tensor:
     exactly the rows the unsharded call would.  Keyword arguments are `mfcc`'s; world size 1 / no process group
     is plain `mfcc`.  ``_max_reduce`` (tests): a callable on the 1-element int32 key tensor instead of the
     all-reduce."""
+    import importlib
     import inspect
 
-    from . import mfcc as _m
+    _m = importlib.import_module(__package__ + ".mfcc")      # (the package exports the function under the same name)
 
     names = [p for p in inspect.signature(_m.mfcc).parameters][1:]
     defaults = {n: p.default for n, p in inspect.signature(_m.mfcc).parameters.items()}

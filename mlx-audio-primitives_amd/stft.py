@@ -125,6 +125,10 @@ _SPECTRUM_LAYOUT = "lines"
 _LINES_N_FFT = (2048, 512, 400, 256)       # the kernels that write / read padded rows (ap_stft_rows_f32, ap_istft_rows_f32)
 
 
+def _spectrum_layout() -> str:
+    return _SPECTRUM_LAYOUT
+
+
 def set_spectrum_layout(layout: str) -> str:
     """Choose "lines" (rows padded to whole 128-byte lines, default) or "dense" for `stft`'s n_fft = 2048
     results; returns the previous setting."""

@@ -433,7 +433,8 @@ int emu_istft16_f32(const float *S, int64_t B, int64_t T, int64_t Ts, int hop, c
     int grid = 0;
     if (ap_prepare_istft16(W, S, tw, B, T, Ts, window, hop, out_offset, out_len, out, &grid) != AP_OK)
         return AP_ERR_UNSUPPORTED;
-    if (grid_cap > 0) grid = grid_cap < (int)W.n_g16 ? grid_cap : (int)W.n_g16;
+    const int64_t n_steps = ((T + 7) / 8) * B;                // the kernel's stretches are in 8-frame steps
+    if (grid_cap > 0) grid = grid_cap < n_steps ? grid_cap : (int)n_steps;
     emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel(W); });
     return AP_OK;
 }

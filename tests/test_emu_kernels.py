@@ -231,7 +231,9 @@ def test_emu_istft_fused(hop, L, B, grid_cap):
 @pytest.mark.parametrize("hop,L,B,grid_cap,Ts", [
     (512, 10752, 3, 2, None),       # T = 22: two 16-frame groups per clip, the second with 6 frames; clip change in a stretch
     (512, 20000, 2, 5, None),       # T = 40: stretches that start inside a clip (8-frame warm-up step)
-    (512, 20000, 2, 3, 48),         # padded rows (whole 128-byte lines)
+    (512, 20000, 2, 3, 48),         # padded rows (whole 128-byte lines); 10 steps on 3 workgroups: a stretch starts on a second step
+    (512, 20000, 2, 7, None),       # 10 steps on 7 workgroups: one- and two-step stretches, odd and even starts
+    (512, 20000, 2, 10, None),      # one step per workgroup
     (512, 11300, 2, 1, None),       # T = 23: second step with 7 frames
     (512, 12400, 2, 4, 30),         # T = 25: the clip ends after a first step (one frame in the last group)
     (1024, 30000, 2, 2, None),

@@ -350,3 +350,28 @@ def test_cfg4_chain_at_full_size():
     shift = 20.0 * np.log10(4.0) * np.sqrt(128.0)
     np.testing.assert_allclose(host(C4[:8, 0] - C[:8, 0]), shift, rtol=0, atol=5e-3)
     np.testing.assert_allclose(host(C4[:8, 1:]), host(C[:8, 1:]), rtol=0, atol=5e-3)
+
+
+def test_melspectrogram_lines_layout_equals_dense():
+    """n_fft = 2048 run kernel with rows padded to whole 32-byte sectors: a strided view with the dense result's bits
+    (aligned 8-frame runs change where a wave's stores fall, not what it computes), for stretches that start anywhere."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    for B, L in ((40, 30000), (256, 220500), (7, 100000)):
+        y = torch.randn((B, L), device="cuda", generator=g) * 0.1
+        stft_mod.set_spectrum_layout("dense")
+        try:
+            D = ap.melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+            assert D.is_contiguous()
+        finally:
+            stft_mod.set_spectrum_layout("lines")
+        V = ap.melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+        assert V.shape == D.shape
+        if D.shape[-1] % 8:
+            assert not V.is_contiguous() and V.stride(1) % 8 == 0 and V.stride(2) == 1
+        assert torch.equal(V, D)
+    ref = ao.melspectrogram(host(y[:2]), sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    np.testing.assert_allclose(host(V[:2]), ref, rtol=1e-4, atol=1e-4)
+    # 80 filters, power 1, reflect padding: the other instantiations of the run kernel
+    V2 = ap.melspectrogram(y, sr=16000, n_fft=2048, hop_length=512, n_mels=80, power=1.0, pad_mode="reflect")
+    ref2 = ao.melspectrogram(host(y[:2]), sr=16000, n_fft=2048, hop_length=512, n_mels=80, power=1.0, pad_mode="reflect")
+    np.testing.assert_allclose(host(V2[:2]), ref2, rtol=1e-4, atol=1e-4)
