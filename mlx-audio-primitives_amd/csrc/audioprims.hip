@@ -122,11 +122,15 @@ static ApFrames8Geom ap_frames8_geom() {
 // n_fft = 16 R mel-spectrogram on the eight-frames-per-wave kernel; *handled = false when it does not apply
 template <int R>
 static int ap_launch_mel8(const ApStftParams &P, int64_t B, const int32_t *plan, const int32_t *desc, float power,
-                          uint32_t *max_key_dev, void *stream, bool *handled) {
+                          uint32_t *max_key_dev, void *stream, bool *handled, int64_t Ts = 0) {
     ApFrames8Params W;
     int grid = 0;
     *handled = false;
     if (ap_prepare_frames8(W, P, B, true, plan, desc, APQ_WAVES, ap_frames8_geom<R>(), &grid) != AP_OK) return AP_OK;
+    if (Ts > 0) {
+        if (Ts < P.T) return AP_OK;
+        W.Ts = Ts;
+    }
     if (max_key_dev) {
         hipError_t e = hipMemsetD32Async((hipDeviceptr_t)max_key_dev, (int)kApKeyMinusInf, 1, (hipStream_t)stream);
         if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipMemsetD32Async: %s", hipGetErrorString(e));
@@ -350,9 +354,14 @@ int ap_melspec_max_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop,
 
 int ap_melspec_rows_fused(int n_fft, int hop, int center, int pad_mode, int n_mels, float power, const int32_t *plan,
                           const int32_t *desc) {
+    (void)hop; (void)center; (void)pad_mode;              // every padding mode has an instantiation of these kernels
+    if (n_fft == 400 || n_fft == 512 || n_fft == 256) {   // eight frames per wave (kernels_frames8.h)
+        if (std::getenv("AP_MEL400_CT")) return 0;
+        return (plan && desc && (desc[0] & AP_PLAN_BANDED) && (desc[0] & AP_PLAN_PARTS) && !(desc[0] & AP_PLAN_FORCE_GENERIC) &&
+                n_mels <= 128 && desc[15] <= 4) ? 1 : 0;
+    }
     static const bool force_wave = std::getenv("AP_MEL2048_WAVE") != nullptr;
     if (force_wave || n_fft != 2048 || !(power == 2.0f || power == 1.0f) || !ap_mel_wave_eligible(n_fft, plan, desc)) return 0;
-    (void)hop; (void)center; (void)pad_mode;              // every padding mode has a run-kernel instantiation
     return (n_mels <= 128 && desc && desc[12] <= 256 && desc[15] <= 4) ? 1 : 0;
 }
 
@@ -401,17 +410,18 @@ int ap_melspec_rows_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop
             return ap_launch_mel_wave_p<1>(W, grid, power, stream);
         }
     }
-    if (rows) AP_FAIL(AP_ERR_UNSUPPORTED, "melspectrogram: padded rows are served by the n_fft = 2048 run kernel only");
     if (n_fft == 400 || n_fft == 512 || n_fft == 256) {     // eight frames per wave (kernels_frames8.h)
         static const bool force_ct = std::getenv("AP_MEL400_CT") != nullptr;     // A/B switch: keep the LDS engine
         if (!force_ct) {
             bool handled = false;
-            rc = n_fft == 400 ? ap_launch_mel8<25>(P, B, plan, desc, power, max_key_dev, stream, &handled)
-                 : n_fft == 512 ? ap_launch_mel8<32>(P, B, plan, desc, power, max_key_dev, stream, &handled)
-                                : ap_launch_mel8<16>(P, B, plan, desc, power, max_key_dev, stream, &handled);
+            const int64_t ts = rows ? row_stride : 0;
+            rc = n_fft == 400 ? ap_launch_mel8<25>(P, B, plan, desc, power, max_key_dev, stream, &handled, ts)
+                 : n_fft == 512 ? ap_launch_mel8<32>(P, B, plan, desc, power, max_key_dev, stream, &handled, ts)
+                                : ap_launch_mel8<16>(P, B, plan, desc, power, max_key_dev, stream, &handled, ts);
             if (rc != AP_OK || handled) return rc;
         }
     }
+    if (rows) AP_FAIL(AP_ERR_UNSUPPORTED, "melspectrogram: padded rows are served by the n_fft = 2048 run kernel and the eight-frame kernels only");
     if (n_fft == 1024) {
         ApMelWave512Params W;
         int grid = 0;
@@ -823,10 +833,11 @@ int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64
     if (n_fft != 2048 || row_stride < T || (row_stride & 1) || row_stride > (1 << 20) ||
         ((reinterpret_cast<uintptr_t>(rebuilt) | reinterpret_cast<uintptr_t>(tprev) | reinterpret_cast<uintptr_t>(R)) & 15))
         AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: padded rows need n_fft = 2048, an even row_stride >= T and 16-byte aligned workspaces");
-    // A/B switches: AP_GL_STREAMS=1 keeps the whole batch on the caller's stream; AP_GL_FUSED_PROJECTION=1 lets the
-    // projection ride in the STFT's store phase (kernels_stft16.h GL = 1: measured equal to the separate pass)
+    // A/B switches: AP_GL_STREAMS=1 keeps the whole batch on the caller's stream; AP_GL_PROJECT_PASS=1 runs the
+    // projection as a pass of its own instead of in the STFT's store phase (kernels_stft16.h GL = 1).  Measured at
+    // 64 x 5 s, 32 iterations: one stream 6.17 / 6.24 ms (separate / fused), two streams 5.64 / 5.44 ms.
     static const int n_streams_env = std::getenv("AP_GL_STREAMS") ? std::atoi(std::getenv("AP_GL_STREAMS")) : 2;
-    static const bool fused = std::getenv("AP_GL_FUSED_PROJECTION") != nullptr;
+    static const bool fused = std::getenv("AP_GL_PROJECT_PASS") == nullptr;
     int n_sub = n_streams_env < 1 ? 1 : (n_streams_env > 4 ? 4 : n_streams_env);
     while (n_sub > 1 && !ap_istft_fused_shape(B / n_sub, T, 2048, hop, out_offset)) --n_sub;
     if (!ap_istft_fused_shape(B / n_sub, T, 2048, hop, out_offset)) AP_FAIL(AP_ERR_UNSUPPORTED, "griffinlim: shape not served with padded rows");

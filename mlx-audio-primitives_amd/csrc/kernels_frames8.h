@@ -53,7 +53,8 @@ struct ApFrames8Params {
     float *out;                // mel: (B, M, T); STFT: (B, n_fft/2 + 1, T) complex64
     unsigned *max_key;
     int64_t L, T, n_clips, groups_per_clip, n_groups;
-    int64_t Ts;                // STFT: complex values between the rows of `out` (T = dense; a multiple of 16 = whole lines)
+    int64_t Ts;                // elements between the rows of `out` (T = dense): complex values for the STFT (a multiple of 16 =
+                               // whole lines), floats for mel (a multiple of 8 = the 8-frame runs are whole sectors)
     int hop, pad, pad_mode, n_mels, wmax;   // pad_mode: used by the PADGEN instantiations only.   wmax: floats per filter row of the LDS weight table (32 or 64, + 4 for even R)
     float power;
     int off_t, off_s, off_win, off_w, off_lo, off_plane, lds_bytes;
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
         // ---- mel contraction: frame g, filters m = q + 8 i --------------------------------
         const int t = t0 + g;
         const float *prow = plane + g * PS;
-        float *ob = P.out + b * (int64_t)M * P.T + t;
+        float *ob = P.out + b * (int64_t)M * P.Ts + t;          // rows Ts floats apart (T = dense)
         // Four steps (32 filters) at a time: one trip of the chunk loop issues 4 weight quads + 16
         // plane values before it uses any of them, so the wave pays one LDS round trip per 4 bins of
         // the longest band in the set instead of one per 4 bins of every filter.
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
             for (int s = 0; s < 4; ++s) {
                 const int m = 8 * (i0 + s) + q;
                 if (i0 + s < NI && m < M && t < Ti) {
-                    ob[(int64_t)m * P.T] = acc[s];
+                    ob[(int64_t)m * P.Ts] = acc[s];
                     vmax = fmaxf(vmax, acc[s]);
                 }
             }

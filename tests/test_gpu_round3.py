@@ -375,3 +375,23 @@ def test_melspectrogram_lines_layout_equals_dense():
     V2 = ap.melspectrogram(y, sr=16000, n_fft=2048, hop_length=512, n_mels=80, power=1.0, pad_mode="reflect")
     ref2 = ao.melspectrogram(host(y[:2]), sr=16000, n_fft=2048, hop_length=512, n_mels=80, power=1.0, pad_mode="reflect")
     np.testing.assert_allclose(host(V2[:2]), ref2, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n_fft,hop,sr,M,L,B", [(400, 160, 16000, 80, 48000, 6), (512, 128, 22050, 64, 30000, 5), (256, 64, 8000, 40, 9000, 7)])
+def test_melspectrogram_lines_layout_of_the_eight_frame_kernels(n_fft, hop, sr, M, L, B):
+    """Whisper front end and the other eight-frames-per-wave mel kernels: rows padded to whole 32-byte sectors are a
+    view with the dense result's bits; oracle at rtol = atol = 1e-4."""
+    rng = np.random.default_rng(n_fft + M)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    yd = dev(y)
+    stft_mod.set_spectrum_layout("dense")
+    try:
+        D = ap.melspectrogram(yd, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M)
+        assert D.is_contiguous()
+    finally:
+        stft_mod.set_spectrum_layout("lines")
+    V = ap.melspectrogram(yd, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M)
+    if D.shape[-1] % 8:
+        assert not V.is_contiguous() and V.stride(1) % 8 == 0
+    assert torch.equal(V, D)
+    np.testing.assert_allclose(host(V), ao.melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M), rtol=1e-4, atol=1e-4)
