@@ -1,12 +1,18 @@
 """Run one operator a few times on the headline-sized batch (for rocprofv3 passes).
-usage: python3 tools/run_op.py {stft|istft|mel|mfcc400|mel1024|mel512|stft512|whisper|gl|mfcc|resample|resfft|reslin} [reps]"""
-import os, sys
+usage: python3 tools/run_op.py {stft|istft|stftd|istftd|mel|mfcc400|mel1024|mel512|stft512|whisper|gl|mfcc|resample|resfft|reslin} [reps] [ramp seconds]
+(stftd / istftd: the dense layout the C entry points ap_stft_f32 / ap_istft_f32 serve; a ramp > 0 runs the operator
+back to back for that long first, so that a --kernel-trace --stats average is a warm-clock number)"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mlx_audio_primitives_amd as ap
 
 op = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ramp = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+if op in ("stftd", "istftd"):
+    ap.set_spectrum_layout("dense")
+    op = op[:-1]
 g = torch.Generator(device="cuda").manual_seed(1)
 if op == "whisper":
     y = torch.randn((256, 160000), device="cuda", generator=g) * 0.1
@@ -48,6 +54,11 @@ else:
         fn = lambda: ap.istft(S, hop_length=512, length=220500)
     else:
         fn = lambda: ap.melspectrogram(y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+t0 = time.time()
+while time.time() - t0 < ramp:
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()

@@ -40,7 +40,9 @@ def write_rows(rows, dst):
 
 
 shutil.copy(os.path.join(ev, "bench.json"), os.path.join(prof, f"{tag}_bench_headline.json"))
-shutil.copy(os.path.join(ev, "configs.json"), os.path.join(prof, f"{tag}_configs_1gpu.json"))
+# every BASELINE config + the reference's published rows: the `configs` object of the same bench line
+_b = json.load(open(os.path.join(ev, "bench.json")))
+json.dump(_b.get("configs", {}), open(os.path.join(prof, f"{tag}_configs_1gpu.json"), "w"), indent=1)
 copy_stats(os.path.join(ev, "kt"), os.path.join(prof, f"{tag}_rocprofv3_kernel_stats_bench.csv"))
 tot = {}
 for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
