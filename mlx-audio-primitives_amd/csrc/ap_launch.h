@@ -671,7 +671,7 @@ static inline int ap_prepare_istft16(ApIstft16Params &W, const float *S, const f
                                      int64_t Ts, const float *window, int hop, int64_t out_offset, int64_t out_len,
                                      float *y, int *grid) {
     if (B <= 0 || T <= 0 || Ts < T || Ts > (1 << 20)) return 1;       // 32-bit row offsets (1024 Ts complex)
-    if (hop < 256 || hop > 2048 || 2048 % hop != 0) return 1;
+    if (hop < 256 || hop > 1024 || 2048 % hop != 0) return 1;           // 256, 512, 1024 (hop = n_fft: the unfused kernels)
     if (out_offset % 4 != 0) return 1;
     W.S = reinterpret_cast<const ap_float2 *>(S);
     W.tw = reinterpret_cast<const ap_float2 *>(tw);
@@ -852,7 +852,7 @@ static inline int ap_prepare_irfft_wave(ApIrfftWaveParams &W, const ApIrfftParam
 // more than the separate overlap-add pass, LDS)
 static inline bool ap_istft_fused_shape(int64_t B, int64_t T, int n_fft, int hop, int64_t out_offset) {
     if (n_fft != 2048 || B <= 0 || T <= 0 || T > (1 << 20)) return false;
-    if (hop < 256 || hop > 2048 || 2048 % hop != 0) return false;
+    if (hop < 256 || hop > 1024 || 2048 % hop != 0) return false;      // 256, 512, 1024 (the gather shifts by log2 hop in {8, 9, 10})
     if (out_offset % 4 != 0) return false;
     return ((T + APS_WAVES - 1) / APS_WAVES) * B >= 64;
 }

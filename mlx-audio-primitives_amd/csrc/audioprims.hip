@@ -591,7 +591,10 @@ static int ap_launch_resample_poly(const float *x, int64_t B, int64_t L, int up,
         const int64_t per_block = AP_BLOCK * 4 * Q;
         const int64_t bprq = (n_out + per_block - 1) / per_block;
         if (bprq * B <= kApMaxGrid) {
+            const int steps = (n_taps + down * 3 + 3) & ~3;
+            static const bool no_unroll = std::getenv("AP_DECIM_NO_UNROLL") != nullptr;    // A/B switch
             auto kern = Q == 4 ? ap_resample_decim_kernel<4> : Q == 2 ? ap_resample_decim_kernel<2> : ap_resample_decim_kernel<1>;
+            if (Q == 2 && steps == 72 && !no_unroll) kern = ap_resample_decim_kernel<2, 72>;
             rc = ap_allow_lds(kern, lds);
             if (rc != AP_OK) return rc;
             hipLaunchKernelGGL(kern, dim3((unsigned)(bprq * B)), dim3(AP_BLOCK), lds,

@@ -11,10 +11,11 @@ int ap_launch_istft16(const float *S, const float *tw, int64_t B, int64_t T, int
     ApIstft16Params W;
     int grid = 0;
     if (ap_prepare_istft16(W, S, tw, B, T, Ts, window, hop, out_offset, out_len, out, &grid) != AP_OK) return 1;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ap_istft2048_g16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, W.lds_bytes);
+    auto kern = hop == 256 ? ap_istft2048_g16_kernel<8> : hop == 512 ? ap_istft2048_g16_kernel<9> : ap_istft2048_g16_kernel<10>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       W.lds_bytes);
     if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipFuncSetAttribute(LDS=%d): %s", W.lds_bytes, hipGetErrorString(e));
-    hipLaunchKernelGGL(ap_istft2048_g16_kernel, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes, (hipStream_t)stream, W);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * APS_WAVES), W.lds_bytes, (hipStream_t)stream, W);
     e = hipGetLastError();
     if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "ap_istft_f32(g16): %s", hipGetErrorString(e));
     return AP_OK;

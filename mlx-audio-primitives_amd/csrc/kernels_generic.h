@@ -343,7 +343,9 @@ struct __attribute__((packed, aligned(4))) ap_rsp_f4u { float x, y, z, w; };   /
 
 // Q = quad-groups of outputs per thread (outputs o0 + 1024 q + 4 tid + r): one tap read serves Q
 // groups, which moves the loop from LDS-issue bound to VALU bound
-template <int Q>
+// STEPS > 0: the window length is a compile-time constant (72 = the 61-tap 3:1 filter of 48 kHz -> 16 kHz): the
+// loop over the window is unrolled and its LDS reads run ahead of the arithmetic
+template <int Q, int STEPS = 0>
 __global__ void __launch_bounds__(AP_BLOCK)
 ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps, int n_taps,
                          int n_pre_remove, int64_t n_out, int64_t blocks_per_row, float *out) {
@@ -353,7 +355,7 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
     const int tid = threadIdx.x;
     const int R = AP_RSP_R;
     const int margin = down * (R - 1);
-    const int steps = (n_taps + margin + 3) & ~3;           // d = 0 .. n_taps-1+margin, rounded up to 4
+    const int steps = STEPS > 0 ? STEPS : ((n_taps + margin + 3) & ~3);   // d = 0 .. n_taps-1+margin, rounded up to 4
     ap_rsp_f4 *hs4 = reinterpret_cast<ap_rsp_f4 *>(ap_smem);
     float *xs = reinterpret_cast<float *>(hs4 + steps);
     const int64_t bid = blockIdx.x;
@@ -394,6 +396,7 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
         acc23[q] = ap_mk(0.0f, 0.0f);
         xq[q] = reinterpret_cast<const ap_rsp_f4 *>(xs + (AP_BLOCK * R * q + R * tid) * down);
     }
+#pragma unroll (STEPS > 0 ? STEPS / 4 : 1)
     for (int d = 0; d < steps; d += 4) {
         const ap_rsp_f4 h0 = hs4[d], h1 = hs4[d + 1], h2 = hs4[d + 2], h3 = hs4[d + 3];
 #pragma unroll

@@ -15,6 +15,8 @@
 #include "kernels_wave.h"
 
 
+// HS = log2(hop): 8, 9 or 10 (the gather's loop bounds and shifts are compile-time constants)
+template <int HS>
 __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApIstft16Params P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -119,14 +121,14 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         }
     };
 
-    const int H = P.hop;
-    const int CN = 2 * APW_NC - H;                              // carry length
-    const int hs = H == 256 ? 8 : (H == 512 ? 9 : 10);           // H = 1 << hs
+    constexpr int H = 1 << HS;                                   // = P.hop
+    constexpr int CN = 2 * APW_NC - H;                           // carry length
+    constexpr int hs = HS;
     const ap_float2 *WINP = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);   // (w[2n], w[2n+1])
     const float *WIN = reinterpret_cast<const float *>(ap_smem + P.off_win);
     const float *INV = reinterpret_cast<const float *>(ap_smem + P.off_inv);
     const float *XF = reinterpret_cast<const float *>(ap_smem);  // frame f at XF + f * 2 APW_X_COMPLEX
-    const int n_own = APS_WAVES * H;                             // positions one 8-frame step completes
+    constexpr int n_own = APS_WAVES * H;                         // positions one 8-frame step completes
 
     // One 8-frame step: frames t0 .. t0 + 7 of clip b from the waves' (xk, xm, xh); `half` picks the carry
     // buffers (steps alternate); `next16 >= 0`: issue the loads of that 16-frame group once xk / xm are consumed.

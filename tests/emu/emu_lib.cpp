@@ -435,7 +435,10 @@ int emu_istft16_f32(const float *S, int64_t B, int64_t T, int64_t Ts, int hop, c
         return AP_ERR_UNSUPPORTED;
     const int64_t n_steps = ((T + 7) / 8) * B;                // the kernel's stretches are in 8-frame steps
     if (grid_cap > 0) grid = grid_cap < n_steps ? grid_cap : (int)n_steps;
-    emu_lds_limit(W.lds_bytes), emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel(W); });
+    emu_lds_limit(W.lds_bytes);
+    if (hop == 256) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<8>(W); });
+    else if (hop == 512) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<9>(W); });
+    else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<10>(W); });
     return AP_OK;
 }
 

@@ -395,3 +395,15 @@ def test_melspectrogram_lines_layout_of_the_eight_frame_kernels(n_fft, hop, sr, 
         assert not V.is_contiguous() and V.stride(1) % 8 == 0
     assert torch.equal(V, D)
     np.testing.assert_allclose(host(V), ao.melspectrogram(y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=M), rtol=1e-4, atol=1e-4)
+
+
+def test_istft_hop_equal_to_n_fft_takes_the_unfused_route():
+    """hop = n_fft = 2048 (no overlap): outside the fused kernels' hop set {256, 512, 1024}; the rectangular window keeps
+    the division well defined."""
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((70, 40960)).astype(np.float32)
+    S = ap.stft(dev(y), n_fft=2048, hop_length=2048, window="boxcar", center=False)
+    yr = host(ap.istft(S, hop_length=2048, window="boxcar", center=False, length=40960))
+    ref = ao.istft(host(S), hop_length=2048, n_fft=2048, window="boxcar", center=False, length=40960)
+    np.testing.assert_allclose(yr, ref, atol=1e-5)
+    assert np.max(np.abs(yr - y)) < 1e-5
