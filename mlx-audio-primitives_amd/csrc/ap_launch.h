@@ -111,6 +111,20 @@ static inline bool ap_resample_decim_eligible(int up, int down, int n_taps, int 
     return false;
 }
 
+// two outputs per thread (ap_resample_decim2_kernel) when their window wastes fewer positions than four outputs' does
+static inline bool ap_resample_decim2_eligible(int up, int down, int n_taps, int *Q, int *lds_bytes) {
+    if (up != 1 || down < 2 || down > 8) return false;
+    const int steps2 = (n_taps + down + 3) & ~3, steps4 = (n_taps + 3 * down + 3) & ~3;
+    if (steps2 >= steps4) return false;
+    const int q = 4;
+    const int span = AP_BLOCK * 2 * q * down + steps2;
+    const int bytes = (steps2 * 2 + span) * (int)sizeof(float);
+    if (bytes > 64 * 1024) return false;
+    *Q = q;
+    *lds_bytes = bytes;
+    return true;
+}
+
 static inline int ap_prepare_stft(ApStftParams &P, const float *y, int64_t B, int64_t L, int n_fft,
                                   int hop, const float *window, const float *tw, int center,
                                   int pad_mode, int64_t T) {

@@ -587,6 +587,18 @@ static int ap_launch_resample_poly(const float *x, int64_t B, int64_t L, int up,
     const int64_t bpr = (n_out + AP_BLOCK - 1) / AP_BLOCK;
     if (bpr * B > kApMaxGrid) AP_FAIL(AP_ERR_UNSUPPORTED, "resample_poly: grid too large");
     int lds = 0, Q = 0;
+    static const bool no_decim2 = std::getenv("AP_DECIM_R4") != nullptr;             // A/B switch: four outputs per thread
+    if (!no_decim2 && ap_resample_decim2_eligible(up, down, n_taps, &Q, &lds)) {
+        const int64_t per_block = AP_BLOCK * 2 * Q;
+        const int64_t bprq = (n_out + per_block - 1) / per_block;
+        if (bprq * B <= kApMaxGrid) {
+            rc = ap_allow_lds(ap_resample_decim2_kernel<4>, lds);
+            if (rc != AP_OK) return rc;
+            hipLaunchKernelGGL(ap_resample_decim2_kernel<4>, dim3((unsigned)(bprq * B)), dim3(AP_BLOCK), lds,
+                               (hipStream_t)stream, x, L, down, taps, n_taps, n_pre_remove, n_out, bprq, out);
+            return ap_check_launch("ap_resample_poly_f32(decim2)");
+        }
+    }
     if (ap_resample_decim_eligible(up, down, n_taps, &Q, &lds)) {
         const int64_t per_block = AP_BLOCK * 4 * Q;
         const int64_t bprq = (n_out + per_block - 1) / per_block;

@@ -429,6 +429,80 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
     }
 }
 
+// The same with TWO outputs per thread and group: their shared window is n_taps + down samples instead of n_taps +
+// 3 down, so fewer of the window's products are the zero-tap ones (61 taps, down 3: 64 positions per output instead
+// of 72).  The kernel runs at the energy ceiling of its packed multiplies and adds, so the instruction
+// count is its time.  Same products, same order, no FMA contraction: bit-exact against SciPy like the kernel above.
+template <int Q>
+__global__ void __launch_bounds__(AP_BLOCK)
+ap_resample_decim2_kernel(const float *x, int64_t L, int down, const float *taps, int n_taps,
+                          int n_pre_remove, int64_t n_out, int64_t blocks_per_row, float *out) {
+#ifndef AP_HOST_EMU
+#pragma clang fp contract(off)
+#endif
+    const int tid = threadIdx.x;
+    const int R = 2;
+    const int steps = (n_taps + down * (R - 1) + 3) & ~3;    // d = 0 .. n_taps-1+down, rounded up to 4
+    ap_rsp_f4 *hs2 = reinterpret_cast<ap_rsp_f4 *>(ap_smem);  // pairs of samples: (tap of output 0, of output 1) x 2
+    float *xs = reinterpret_cast<float *>(ap_smem) + steps * R;
+    const int64_t bid = blockIdx.x;
+    const int64_t b = bid / blocks_per_row;
+    const int64_t o0 = (bid - b * blocks_per_row) * (AP_BLOCK * R * Q);
+    const int span = AP_BLOCK * R * Q * down + steps;
+    const int64_t s0 = (o0 + n_pre_remove) * (int64_t)down - (n_taps - 1);
+    const float *xb = x + b * L;
+    for (int i = tid; i < steps * R; i += AP_BLOCK) {
+        const int d = i >> 1, r = i & 1;
+        const int j = (n_taps - 1) - d + down * r;            // output r sees sample d through tap j
+        reinterpret_cast<float *>(hs2)[i] = (j >= 0 && j < n_taps) ? taps[j] : 0.0f;
+    }
+    for (int i = 4 * tid; i < span; i += 4 * AP_BLOCK) {
+        const int64_t g = s0 + i;
+        ap_rsp_f4 v;
+        if (g >= 0 && g + 3 < L) {
+            const ap_rsp_f4u u = *reinterpret_cast<const ap_rsp_f4u *>(xb + g);
+            v.x = u.x; v.y = u.y; v.z = u.z; v.w = u.w;
+        } else {
+            v.x = (g >= 0 && g < L) ? xb[g] : 0.0f;
+            v.y = (g + 1 >= 0 && g + 1 < L) ? xb[g + 1] : 0.0f;
+            v.z = (g + 2 >= 0 && g + 2 < L) ? xb[g + 2] : 0.0f;
+            v.w = (g + 3 >= 0 && g + 3 < L) ? xb[g + 3] : 0.0f;
+        }
+        *reinterpret_cast<ap_rsp_f4 *>(xs + i) = v;
+    }
+    AP_LDS_BARRIER();
+    // group q of this thread starts its window at xs[(512 q + 2 tid) * down] (8-byte aligned)
+    ap_float2 acc[Q];
+    const ap_float2 *xq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        acc[q] = ap_mk(0.0f, 0.0f);
+        xq[q] = reinterpret_cast<const ap_float2 *>(xs + (AP_BLOCK * R * q + R * tid) * down);
+    }
+    for (int d = 0; d < steps; d += 4) {
+        const ap_rsp_f4 h01 = hs2[d >> 1], h23 = hs2[(d >> 1) + 1];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const ap_float2 xa = xq[q][d >> 1], xb2 = xq[q][(d >> 1) + 1];
+            AP_RSP_MAC(acc[q], h01.x, h01.y, xa.x);
+            AP_RSP_MAC(acc[q], h01.z, h01.w, xa.y);
+            AP_RSP_MAC(acc[q], h23.x, h23.y, xb2.x);
+            AP_RSP_MAC(acc[q], h23.z, h23.w, xb2.y);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int64_t o = o0 + (int64_t)(AP_BLOCK * R) * q + (int64_t)R * tid;
+        float *dst = out + b * n_out + o;
+        if (o + 1 < n_out && ((b * n_out + o) & 1) == 0) {
+            *reinterpret_cast<ap_float2 *>(dst) = acc[q];
+        } else {
+            if (o < n_out) dst[0] = acc[q].x;
+            if (o + 1 < n_out) dst[1] = acc[q].y;
+        }
+    }
+}
+
 // reference resample.py:183-195: float64 positions and interpolation, float32 result
 AP_KERNEL void __launch_bounds__(AP_BLOCK)
 ap_resample_linear_kernel(const float *x, int64_t B, int64_t L, int64_t n_out, double scale, float *out) {

@@ -316,6 +316,14 @@ int emu_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down
     int rc = ap_prepare_resample_poly(x, B, L, up, down, taps, n_taps, n_pre_remove, n_out, out, &bpr);
     if (rc != AP_OK) return rc;
     int lds = 0, Q = 0;
+    if (emu_decim2 && ap_resample_decim2_eligible(up, down, n_taps, &Q, &lds)) {
+        const int64_t per_block = AP_BLOCK * 2 * Q;
+        const int64_t bprq = (n_out + per_block - 1) / per_block;
+        emu_lds_limit(lds), emu_launch((unsigned)(bprq * B), AP_BLOCK, [&] {
+            ap_resample_decim2_kernel<4>(x, L, down, taps, n_taps, n_pre_remove, n_out, bprq, out);
+        });
+        return AP_OK;
+    }
     if (ap_resample_decim_eligible(up, down, n_taps, &Q, &lds)) {
         const int64_t per_block = AP_BLOCK * 4 * Q;
         const int64_t bprq = (n_out + per_block - 1) / per_block;
