@@ -208,7 +208,9 @@ def resample_poly_taps(up, down):
     return taps, npr.value
 
 
-def resample_poly(x, up, down):
+def resample_poly(x, up, down, two_outputs=True):
+    """two_outputs: let the two-outputs-per-thread decimator (ap_resample_decim2_kernel) serve the shapes it applies to."""
+    lib().emu_set_decim2(int(two_outputs))
     x = np.ascontiguousarray(x, np.float32)
     B, L = x.shape
     taps, npr = resample_poly_taps(up, down)

@@ -310,6 +310,9 @@ int emu_irfft_frames_f32(const float *S, int64_t B, int64_t T, int n_fft, const 
     return AP_OK;
 }
 
+static int emu_decim2 = 1;         // 0: keep the four-outputs-per-thread decimator (tests run both)
+void emu_set_decim2(int on) { emu_decim2 = on; }
+
 int emu_resample_poly_f32(const float *x, int64_t B, int64_t L, int up, int down, const float *taps,
                           int n_taps, int n_pre_remove, int64_t n_out, float *out) {
     int64_t bpr;

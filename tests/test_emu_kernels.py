@@ -319,10 +319,13 @@ def test_emu_resample_poly_bit_exact_vs_scipy():
     # LDS-tiled decimator (up == 1): ragged lengths, several workgroups, down = 2..5
     import scipy.signal
     rng = np.random.default_rng(1)
-    for down, L in ((3, 4800), (2, 5001), (4, 2049), (5, 777), (3, 100)):
+    # (both register blockings: two outputs per thread where that window wastes fewer positions - down 3, 4, 5, 7 -
+    #  and four)
+    for down, L in ((3, 4800), (2, 5001), (4, 2049), (5, 777), (3, 100), (7, 9000), (3, 20011)):
         xx = rng.standard_normal((2, L)).astype(np.float32)
-        np.testing.assert_array_equal(eb.resample_poly(xx, 1, down),
-                                      scipy.signal.resample_poly(xx, 1, down, axis=-1).astype(np.float32))
+        want = scipy.signal.resample_poly(xx, 1, down, axis=-1).astype(np.float32)
+        np.testing.assert_array_equal(eb.resample_poly(xx, 1, down), want)
+        np.testing.assert_array_equal(eb.resample_poly(xx, 1, down, two_outputs=False), want)
     # LDS-tiled interpolating cases (up > 1): several workgroups, ragged ends, large and tiny ratios
     for up, down, L in ((160, 147, 5000), (2, 1, 3001), (3, 2, 2500), (4, 3, 1025), (2, 9, 9001), (7, 5, 60), (441, 160, 400)):
         xx = rng.standard_normal((2, L)).astype(np.float32)
