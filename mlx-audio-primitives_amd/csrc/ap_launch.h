@@ -374,6 +374,7 @@ static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bo
     W.L = P.L;
     W.T = P.T;
     W.Ts = P.T;                                            // dense rows; the padded-row entry points overwrite it
+    W.plain_stores = 1;
     W.n_clips = B;
     W.groups_per_clip = (P.T + 7) / 8;
     W.n_groups = W.groups_per_clip * B;
@@ -497,6 +498,7 @@ static inline int ap_prepare_mel_wave512(W512 &W, const ApStftParams &P, int64_t
     W.out = P.out_mel;
     W.max_key = nullptr;
     W.L = P.L;
+    W.Ts = P.T;                                                // dense rows; ap_melspec_rows_f32 overwrites it
     W.T = P.T;
     W.n_clips = B;
     W.hop = P.hop;

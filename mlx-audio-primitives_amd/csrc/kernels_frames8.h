@@ -55,6 +55,7 @@ struct ApFrames8Params {
     int64_t L, T, n_clips, groups_per_clip, n_groups;
     int64_t Ts;                // elements between the rows of `out` (T = dense): complex values for the STFT (a multiple of 16 =
                                // whole lines), floats for mel (a multiple of 8 = the 8-frame runs are whole sectors)
+    int plain_stores;          // mel: 1 = no lane transpose before the stores (default; AP_MEL8_TRANSPOSED_STORES=1 turns it on)
     int hop, pad, pad_mode, n_mels, wmax;   // pad_mode: used by the PADGEN instantiations only.   wmax: floats per filter row of the LDS weight table (32 or 64, + 4 for even R)
     float power;
     int off_t, off_s, off_win, off_w, off_lo, off_plane, lds_bytes;
@@ -346,6 +347,8 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
 
     float vmax = -INFINITY;
     const int Ti = (int)P.T;
+    const int gt = lane & 7, qt = lane >> 3;                  // store role: frame gt of the rows 8 i + qt
+    const int lane_t = (gt << 3) | qt;                        // ... whose value lane (g = gt, q = qt) computed
     apq_group_loop<R, PADGEN>(P, Ln, Tt + q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
         // ---- paired real split + power: this lane's bins k = k1 + R k2 --------------------
         float *pl = plane + g * PS + BS * Ln.k2;
@@ -358,7 +361,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
         // ---- mel contraction: frame g, filters m = q + 8 i --------------------------------
         const int t = t0 + g;
         const float *prow = plane + g * PS;
-        float *ob = P.out + b * (int64_t)M * P.Ts + t;          // rows Ts floats apart (T = dense)
+        float *obt = P.out + b * (int64_t)M * P.Ts + t0 + gt;   // rows Ts floats apart (T = dense); transposed store role
         // Four steps (32 filters) at a time: one trip of the chunk loop issues 4 weight quads + 16
         // plane values before it uses any of them, so the wave pays one LDS round trip per 4 bins of
         // the longest band in the set instead of one per 4 bins of every filter.
@@ -392,13 +395,21 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
                     acc[s] = fmaf(w[s].w, pv[s][3], acc[s]);
                 }
             }
+            // Lane (g, q) = 8 g + q has frame g of row 8 i + q: stored as they are, the eight lanes of a row's 32-byte
+            // run are eight lanes apart and the write path does not merge them (WRITE_SIZE 1.6-1.8 x the array).  One
+            // lane permute per value turns the 8 x 8 lane block over: lane 8 q + g stores (row 8 i + q, frame g), so a
+            // run is eight ADJACENT lanes = one request.
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int m = 8 * (i0 + s) + q;
-                if (i0 + s < NI && m < M && t < Ti) {
-                    ob[(int64_t)m * P.Ts] = acc[s];
-                    vmax = fmaxf(vmax, acc[s]);
+                if (i0 + s < NI && m < M && t < Ti) vmax = fmaxf(vmax, acc[s]);
+                if (P.plain_stores) {                              // default (uniform): every lane stores its own value
+                    if (i0 + s < NI && m < M && t < Ti) P.out[b * (int64_t)M * P.Ts + t + (int64_t)m * P.Ts] = acc[s];
+                    continue;
                 }
+                const float v = apq_lane_read(acc[s], lane_t);
+                const int mt = 8 * (i0 + s) + qt;
+                if (i0 + s < NI && mt < M && t0 + gt < Ti) obt[(int64_t)mt * P.Ts] = v;
             }
         }
         AP_WAVE_SYNC();

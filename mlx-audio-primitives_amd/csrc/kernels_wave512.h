@@ -106,6 +106,7 @@ struct ApMelWave512Params {
     float *out;                // (B, M, T)
     unsigned *max_key;
     int64_t L, T, n_clips;
+    int64_t Ts;                // floats between the rows of `out` (T = dense; a multiple of 8 = whole sectors)
     int hop, pad, pad_mode, n_mels, n_parts, n_quads, n_slots, max_row_parts, partial_stride, hopj;
     float power;
     int off_tw1, off_tw2, off_win, off_wq, off_parts, off_partial, lds_bytes;
@@ -186,11 +187,18 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[(j + HOPJ * ROT) & 7] = ld2(b, base, base + 2 * (lane + 64 * j));
         };
-        load_frame(t, std::integral_constant<int, 0>());
+        // U = 4: the stretch's first frame takes the register rotation t mod 4 and the run half (t / 4) mod 2, so frame t
+        // sits at position t mod 8 of the run registers and full runs are the clip's frames 8 k .. 8 k + 7: aligned
+        // 32-byte pieces of their rows (kernels_mel2048.h; whole sectors when the rows are padded to a multiple of 8)
+        const int r0 = U == 4 ? (t & 3) : 0;
+        if (r0 == 1) load_frame(t, std::integral_constant<int, 1 % U>());
+        else if (r0 == 2) load_frame(t, std::integral_constant<int, 2 % U>());
+        else if (r0 == 3) load_frame(t, std::integral_constant<int, 3 % U>());
+        else load_frame(t, std::integral_constant<int, 0>());
         float acc0[8], acc1[8];                   // the run's values of rows lane and lane + 64
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-        int nrun = 0, half = 0;
+        int nrun = 0, half = U == 4 ? ((t >> 2) & 1) : 0;
         int64_t f = f_lo;
 
         auto frame = [&](auto rot_tag) -> bool {
@@ -310,12 +318,12 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
             // ---- store the run when it is full, the clip ends or the stretch ends ---------------------
             if ((U == 1 ? nrun == 8 : pos == 7) || clip_ends || !more) {
                 const int first = pos - nrun + 1;
-                float *ob = P.out + b * (int64_t)M * P.T + (t - nrun + 1);
+                float *ob = P.out + b * (int64_t)M * P.Ts + (t - nrun + 1);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = lane + 64 * i;
                     if (row < M) {
-                        float *dst = ob + (int64_t)row * P.T;
+                        float *dst = ob + (int64_t)row * P.Ts;
                         const float *src = i == 0 ? acc0 : acc1;
                         if (nrun == 8) {            // 32 contiguous bytes: two 16-byte stores (4-byte aligned)
                             ap_rsp_f4u lo, hi;
@@ -339,11 +347,13 @@ __global__ void __launch_bounds__(64 * APH_WAVES, 3) ap_mel1024_wave_kernel(ApMe
         if (U == 1) {
             while (frame(std::integral_constant<int, 0>())) {}
         } else {
+            int skip = r0;                        // the first trip enters at rotation r0 (uniform branches)
             for (;;) {
-                if (!frame(std::integral_constant<int, 0>())) break;
-                if (!frame(std::integral_constant<int, 1 % U>())) break;
-                if (!frame(std::integral_constant<int, 2 % U>())) break;
+                if (skip <= 0 && !frame(std::integral_constant<int, 0>())) break;
+                if (skip <= 1 && !frame(std::integral_constant<int, 1 % U>())) break;
+                if (skip <= 2 && !frame(std::integral_constant<int, 2 % U>())) break;
                 if (!frame(std::integral_constant<int, 3 % U>())) break;
+                skip = 0;
                 half ^= 1;
             }
         }

@@ -377,7 +377,8 @@ def test_melspectrogram_lines_layout_equals_dense():
     np.testing.assert_allclose(host(V2[:2]), ref2, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("n_fft,hop,sr,M,L,B", [(400, 160, 16000, 80, 48000, 6), (512, 128, 22050, 64, 30000, 5), (256, 64, 8000, 40, 9000, 7)])
+@pytest.mark.parametrize("n_fft,hop,sr,M,L,B", [(400, 160, 16000, 80, 48000, 6), (512, 128, 22050, 64, 30000, 5), (256, 64, 8000, 40, 9000, 7),
+                                                  (1024, 256, 22050, 80, 50000, 9), (1024, 300, 22050, 128, 40000, 4)])
 def test_melspectrogram_lines_layout_of_the_eight_frame_kernels(n_fft, hop, sr, M, L, B):
     """Whisper front end and the other eight-frames-per-wave mel kernels: rows padded to whole 32-byte sectors are a
     view with the dense result's bits; oracle at rtol = atol = 1e-4."""
