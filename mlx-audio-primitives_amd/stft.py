@@ -120,8 +120,10 @@ def _frame_count(signal_length: int, n_fft: int, hop_length: int, center: bool, 
 # `griffinlim` read such views in place).  The values, shape and dtype are the reference's; only
 # `.is_contiguous()` differs - as it does for the reference itself, whose result is the transposed view
 # mx.transpose(…, (0, 2, 1)) of its (B, T, F) transform (stft.py:216).  "dense": a contiguous array
-# (what the C entry point ap_stft_f32 always writes).
-_SPECTRUM_LAYOUT = "lines"
+# (what the C entry point ap_stft_f32 always writes).  AP_SPECTRUM_LAYOUT=dense in the environment sets the default.
+import os as _os
+
+_SPECTRUM_LAYOUT = "dense" if _os.environ.get("AP_SPECTRUM_LAYOUT", "lines") == "dense" else "lines"
 _LINES_N_FFT = (2048, 512, 400, 256)       # the kernels that write / read padded rows (ap_stft_rows_f32, ap_istft_rows_f32)
 
 

@@ -408,3 +408,47 @@ def test_istft_hop_equal_to_n_fft_takes_the_unfused_route():
     ref = ao.istft(host(S), hop_length=2048, n_fft=2048, window="boxcar", center=False, length=40960)
     np.testing.assert_allclose(yr, ref, atol=1e-5)
     assert np.max(np.abs(yr - y)) < 1e-5
+
+
+def test_random_shapes_lines_vs_dense_vs_oracle():
+    """Randomised shapes through the round-3 kernels: stft / istft / melspectrogram with padded and dense rows and the
+    oracle, n_fft 2048 with hops 256 / 512 / 1024 and odd ones, T below, at and above multiples of 16, tiny batches."""
+    rng = np.random.default_rng(2026)
+    for trial in range(14):
+        hop = int(rng.choice([256, 512, 1024, 512, 512, 300, 441]))
+        T = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 64, 100, 216]))
+        B = int(rng.choice([1, 2, 3, 37, 64]))
+        center = bool(rng.integers(0, 2)) or T == 1
+        L = (T - 1) * hop + (0 if center else 2048) + int(rng.integers(0, hop))
+        if L < (2048 if not center else 1):
+            L = 2048
+        y = rng.standard_normal((B, L)).astype(np.float32)
+        yd = dev(y)
+        R = ao.stft(y, n_fft=2048, hop_length=hop, center=center)
+        stft_mod.set_spectrum_layout("dense")
+        try:
+            D = ap.stft(yd, n_fft=2048, hop_length=hop, center=center)
+            Md = ap.melspectrogram(yd, sr=22050, n_fft=2048, hop_length=hop, n_mels=64, center=center)
+        finally:
+            stft_mod.set_spectrum_layout("lines")
+        V = ap.stft(yd, n_fft=2048, hop_length=hop, center=center)
+        Mv = ap.melspectrogram(yd, sr=22050, n_fft=2048, hop_length=hop, n_mels=64, center=center)
+        tag = f"trial {trial}: hop {hop} T {R.shape[-1]} B {B} center {center}"
+        assert V.shape == R.shape, tag
+        np.testing.assert_allclose(host(D), R, rtol=1e-4, atol=1e-4, err_msg=tag)
+        assert torch.equal(torch.view_as_real(V), torch.view_as_real(D)), tag
+        assert torch.equal(Mv, Md), tag
+        np.testing.assert_allclose(host(Mv), ao.melspectrogram(y, sr=22050, n_fft=2048, hop_length=hop, n_mels=64, center=center),
+                                   rtol=1e-4, atol=1e-4, err_msg=tag)
+        for S in (V, D, stft_mod.stft_padded_rows(yd, n_fft=2048, hop_length=hop, center=center, row_multiple=48)):
+            yr = ap.istft(S, hop_length=hop, center=center, length=L)
+            ref = ao.istft(R, hop_length=hop, n_fft=2048, center=center, length=L)
+            if center:
+                np.testing.assert_allclose(host(yr), ref, atol=2e-5, err_msg=tag)
+            else:                       # compare where the window sum is not tiny (see tests/test_emu_kernels.py)
+                wss = np.zeros(L + 4096)
+                w = ao.padded_window("hann", 2048, 2048).astype(np.float64) ** 2
+                for t in range(R.shape[-1]):
+                    wss[t * hop:t * hop + 2048] += w
+                ok = wss[:L] > 1e-2
+                np.testing.assert_allclose(host(yr)[:, ok], ref[:, ok], atol=2e-5, err_msg=tag)
