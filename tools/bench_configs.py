@@ -99,6 +99,18 @@ def run_configs(ramp_s=0.5, which=None):
         ms = steady(lambda i: ap.istft(Ss[i % N_ROT], hop_length=512, length=220500), ramp_s=ramp_s)
         rep["headline_istft2048"] = rec(ms, 256 * T, (8 * 1025 + 4 * 512) * 256 * T, unit="frames")
         del Ss
+        # the same two operators on DENSE rows: what the C entry points ap_stft_f32 / ap_istft_f32 (the drop-in for the
+        # reference's binding) read and write; `stft()` itself returns line-padded rows
+        prev = ap.set_spectrum_layout("dense")
+        try:
+            ms = steady(lambda i: ap.stft(ys[i % N_ROT], n_fft=2048, hop_length=512), ramp_s=ramp_s)
+            rep["headline_stft2048_dense_rows"] = rec(ms, 256 * T, (4 * 512 + 8 * 1025) * 256 * T, unit="frames")
+            Ss = [ap.stft(y, n_fft=2048, hop_length=512) for y in ys]
+            ms = steady(lambda i: ap.istft(Ss[i % N_ROT], hop_length=512, length=220500), ramp_s=ramp_s)
+            rep["headline_istft2048_dense_rows"] = rec(ms, 256 * T, (8 * 1025 + 4 * 512) * 256 * T, unit="frames")
+            del Ss
+        finally:
+            ap.set_spectrum_layout(prev)
     if "other" in which:
         ms = steady(lambda i: ap.melspectrogram(ys[i % N_ROT], sr=22050, n_fft=1024, hop_length=256, n_mels=80), ramp_s=ramp_s)
         T1 = 1 + 220500 // 256
