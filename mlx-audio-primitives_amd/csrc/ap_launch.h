@@ -392,6 +392,10 @@ static inline int ap_prepare_frames8(W8 &W, const ApStftParams &P, int64_t B, bo
     W.off_w = off; off += m8 * W.wmax * 4;
     W.off_lo = off; off += ap_align16((m8 + m8 / 8) * 4);
     W.off_plane = off; off += mel ? n_waves * 8 * G.plane_floats * 4 : 0;
+    // mel: a [m8][8] output tile per wave so that a group's rows leave as 16-byte stores (off_stage = 0: every lane
+    // stores its own values); dropped when it does not fit
+    W.off_stage = 0;
+    if (mel && off + n_waves * m8 * 8 * 4 <= AP_LDS_MAX) { W.off_stage = off; off += n_waves * m8 * 8 * 4; }
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;
     int64_t g = (W.n_groups + (int64_t)n_waves * 2 - 1) / ((int64_t)n_waves * 2);    // >= 2 groups per wave

@@ -58,7 +58,7 @@ struct ApFrames8Params {
     int plain_stores;          // mel: 1 = no lane transpose before the stores (default; AP_MEL8_TRANSPOSED_STORES=1 turns it on)
     int hop, pad, pad_mode, n_mels, wmax;   // pad_mode: used by the PADGEN instantiations only.   wmax: floats per filter row of the LDS weight table (32 or 64, + 4 for even R)
     float power;
-    int off_t, off_s, off_win, off_w, off_lo, off_plane, lds_bytes;
+    int off_t, off_s, off_win, off_w, off_lo, off_plane, off_stage, lds_bytes;   // off_stage: 0 = no output tile
 };
 
 #ifdef AP_HOST_EMU
@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
 
     float vmax = -INFINITY;
     const int Ti = (int)P.T;
+    float *stage = P.off_stage ? reinterpret_cast<float *>(ap_smem + P.off_stage) + wave * (M8 * 8) : nullptr;
     const int gt = lane & 7, qt = lane >> 3;                  // store role: frame gt of the rows 8 i + qt
     const int lane_t = (gt << 3) | qt;                        // ... whose value lane (g = gt, q = qt) computed
     apq_group_loop<R, PADGEN>(P, Ln, Tt + q * BS, WINP, wave, [&](ap_float2 (&v)[R], int64_t b, int t0) {
@@ -403,7 +404,11 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
             for (int s = 0; s < 4; ++s) {
                 const int m = 8 * (i0 + s) + q;
                 if (i0 + s < NI && m < M && t < Ti) vmax = fmaxf(vmax, acc[s]);
-                if (P.plain_stores) {                              // default (uniform): every lane stores its own value
+                if (stage) {                                       // (uniform) into the wave's output tile
+                    if (i0 + s < NI) stage[m * 8 + g] = acc[s];
+                    continue;
+                }
+                if (P.plain_stores) {                              // (uniform): every lane stores its own value
                     if (i0 + s < NI && m < M && t < Ti) P.out[b * (int64_t)M * P.Ts + t + (int64_t)m * P.Ts] = acc[s];
                     continue;
                 }
@@ -413,6 +418,26 @@ __global__ void __launch_bounds__(64 * APQ_WAVES, 2) ap_mel8_wave_kernel(ApFrame
             }
         }
         AP_WAVE_SYNC();
+        if (stage) {
+            // the tile leaves as 16-byte pieces: lane pair (2 r, 2 r + 1) stores the two halves of row r's 8-frame run
+            // (a quarter of the store instructions, and the write path sees 32 contiguous bytes from adjacent lanes)
+            float *orow = P.out + b * (int64_t)M * P.Ts + t0;
+            for (int e = lane; e < 2 * M; e += 64) {
+                const int row = e >> 1, h4 = (e & 1) * 4;
+                const ap_float4 v4 = *reinterpret_cast<const ap_float4 *>(stage + row * 8 + h4);
+                float *dst = orow + (int64_t)row * P.Ts + h4;
+                if (t0 + h4 + 3 < Ti) {
+                    ap_rsp_f4u u;
+                    u.x = v4.x; u.y = v4.y; u.z = v4.z; u.w = v4.w;
+                    *reinterpret_cast<ap_rsp_f4u *>(dst) = u;
+                } else {
+                    if (t0 + h4 < Ti) dst[0] = v4.x;
+                    if (t0 + h4 + 1 < Ti) dst[1] = v4.y;
+                    if (t0 + h4 + 2 < Ti) dst[2] = v4.z;
+                }
+            }
+            AP_WAVE_SYNC();
+        }
     });
     if (P.max_key) {                  // one atomic per wave: lanes -> LDS -> lane 0
         AP_WAVE_SYNC();
