@@ -14,3 +14,7 @@ int ap_launch_stft16_gl(const ApStftParams &P, int64_t B, int64_t Ts, const floa
 // Returns AP_OK, an error status, or 1 when the shape is not served.
 int ap_launch_istft16(const float *S, const float *tw, int64_t B, int64_t T, int64_t Ts, const float *window, int hop,
                       int64_t out_offset, int64_t out_len, float *out, void *stream);
+
+// Upper bound on the persistent grids of the two launchers above (0 = none): the Griffin-Lim loop runs chains on
+// several streams and may want their kernels side by side on disjoint CUs instead of queued behind each other.
+extern thread_local int ap_g16_grid_cap;

@@ -875,6 +875,8 @@ int ap_griffinlim_rows_f32(const float *S, const float *angles, int64_t B, int64
                                 momentum, rebuilt, tprev, R, y, fused, (hipStream_t)stream);
     if (hipEventRecord(gs->fork, (hipStream_t)stream) != hipSuccess) AP_FAIL(AP_ERR_HIP, "griffinlim: hipEventRecord failed");
     int rc = AP_OK;
+    static const int cap_env = std::getenv("AP_GL_GRID_CAP") ? std::atoi(std::getenv("AP_GL_GRID_CAP")) : 0;
+    struct CapGuard { int old; CapGuard(int v) : old(ap_g16_grid_cap) { ap_g16_grid_cap = v; } ~CapGuard() { ap_g16_grid_cap = old; } } guard(cap_env);
     const int64_t spec = 1025 * T, wsp = 1025 * row_stride * 2;
     for (int i = 0; i < n_sub; ++i) {
         const int64_t b0 = B * i / n_sub, b1 = B * (i + 1) / n_sub;

@@ -11,6 +11,7 @@ int ap_launch_istft16(const float *S, const float *tw, int64_t B, int64_t T, int
     ApIstft16Params W;
     int grid = 0;
     if (ap_prepare_istft16(W, S, tw, B, T, Ts, window, hop, out_offset, out_len, out, &grid) != AP_OK) return 1;
+    if (ap_g16_grid_cap > 0 && grid > ap_g16_grid_cap) grid = ap_g16_grid_cap;
     auto kern = hop == 256 ? ap_istft2048_g16_kernel<8> : hop == 512 ? ap_istft2048_g16_kernel<9> : ap_istft2048_g16_kernel<10>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        W.lds_bytes);

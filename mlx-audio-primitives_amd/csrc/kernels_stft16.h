@@ -184,16 +184,20 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                     gpv[c][i] = ok ? pb[bin * Ts + sf] : ap_mk(0.0f, 0.0f);
                 }
             if (tid < APS16_G) gpv_mid = ok ? pb[(APW_NC / 2) * Ts + sf] : ap_mk(0.0f, 0.0f);
-            // (all magnitudes are fetched after the transforms: chunk 0 waits for them, the other chunks do not)
         }
         if (PADGEN) load_frame(group, 0);
         transform(xkA, xmA, zhA, group, 1);
+        if (GL) {                                  // the first four chunks' magnitudes land under the second transform
+            AP_SCHED_FENCE();
+            gl_load_mag(0, 4);
+            AP_SCHED_FENCE();
+        }
         if (PADGEN) load_frame(group, 1);
         transform(xkB, xmB, zhB, -1, 0);
         // the next group's first frame lands under the store phase (during the second transform the
         // registers hold the first frame's spectrum instead)
         AP_SCHED_FENCE();
-        if (GL) gl_load_mag(0, 8);
+        if (GL) gl_load_mag(4, 8);
         // (GL: the projection's operands fill the registers until half of the chunks are out: the prefetch waits)
         if (!GL && !PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
         AP_SCHED_FENCE();

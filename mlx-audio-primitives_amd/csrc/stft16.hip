@@ -6,8 +6,11 @@
 #include "ap_tu.h"
 #include "kernels_stft16.h"
 
+thread_local int ap_g16_grid_cap = 0;
+
 template <int PADGEN, int ALIGNED, int NT, int GL = 0>
 static int ap_stft16_go(const ApStft16Params &W, int grid, void *stream) {
+    if (ap_g16_grid_cap > 0 && grid > ap_g16_grid_cap) grid = ap_g16_grid_cap;
     auto kern = ap_stft2048_g16_kernel<PADGEN, ALIGNED, NT, GL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, W.lds_bytes);
