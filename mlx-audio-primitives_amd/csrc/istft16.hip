@@ -13,6 +13,8 @@ int ap_launch_istft16(const float *S, const float *tw, int64_t B, int64_t T, int
     if (ap_prepare_istft16(W, S, tw, B, T, Ts, window, hop, out_offset, out_len, out, &grid) != AP_OK) return 1;
     if (ap_g16_grid_cap > 0 && grid > ap_g16_grid_cap) grid = ap_g16_grid_cap;
     auto kern = hop == 256 ? ap_istft2048_g16_kernel<8> : hop == 512 ? ap_istft2048_g16_kernel<9> : ap_istft2048_g16_kernel<10>;
+    static const bool loose = std::getenv("AP_ISTFT16_LOOSE") != nullptr;            // A/B switch: the unfenced transform
+    if (loose && hop == 512) kern = ap_istft2048_g16_kernel<9, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        W.lds_bytes);
     if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipFuncSetAttribute(LDS=%d): %s", W.lds_bytes, hipGetErrorString(e));

@@ -294,3 +294,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         }
     }
 }
+
+// (Round 3 also measured a software-pipelined form of the ALIGNED kernel: the transform cut at its two wave-private LDS
+//  hand-offs into three resumable stages, and the eight store rounds of group g placed between the stages of group
+//  g + 1's two transforms, so that a round's latencies sit under a stage's arithmetic.  0.335-0.344 ms against 0.285 ms
+//  for the phase-by-phase kernel above on the same box: every round is a workgroup barrier, and eight barriers spread
+//  through the transforms make the waves wait for each other's stages.  Not in the build; profiles/README.md.)

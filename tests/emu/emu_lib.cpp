@@ -174,7 +174,7 @@ int emu_stft16_f32(const float *y, int64_t B, int64_t L, int hop, const float *w
     ApStft16Params W;
     int grid = 0, aligned = 0;
     if (ap_prepare_stft16(W, P, B, Ts, &grid, &aligned) != AP_OK) return AP_ERR_UNSUPPORTED;
-    if (force_unaligned) aligned = 0;
+    if (force_unaligned == 1) aligned = 0;
     if (grid > grid_cap) grid = grid_cap;   // exercise the persistent group loop and the carries
     const bool pg = !ap_clip_loads_ok(W);
     emu_lds_limit(W.lds_bytes);

@@ -68,6 +68,10 @@ def test_emu_stft(n_fft, hop, L, B, pad_mode, center):
     # ... and the carry path on the same layout (phi = 0 everywhere: every store lags a whole group)
     (512, 20000, 2, "constant", True, 48, 3, 0, True),
     (512, 20000, 1, "constant", True, 45, 2, 7, False),        # padded, but not to a line
+    # one group per workgroup, many groups per workgroup, odd hop (index-remapped loads) on padded rows
+    (512, 20000, 2, "constant", True, 48, 6, 0, False),
+    (512, 60000, 1, "constant", False, 128, 1, 0, False),
+    (255, 9000, 2, "constant", True, 48, 2, 0, False),
 ])
 def test_emu_stft16(hop, L, B, pad_mode, center, Ts, grid_cap, misalign, force_unaligned):
     """kernels_stft16.h (n_fft = 2048, 16 frames per group, 128-byte row windows) on the CPU."""
@@ -80,7 +84,7 @@ def test_emu_stft16(hop, L, B, pad_mode, center, Ts, grid_cap, misalign, force_u
     np.testing.assert_allclose(S, R, rtol=1e-4, atol=1e-4)
     T = R.shape[-1]
     Tr = T if Ts is None else Ts
-    assert aligned == int(Tr % 16 == 0 and misalign == 0 and not force_unaligned)
+    assert aligned == int(Tr % 16 == 0 and misalign == 0 and force_unaligned != True)
     # nothing outside the T frames of every row was touched (row padding, guard floats either side)
     n = B * 1025 * Tr
     assert np.all(raw[:off] == -777.0) and np.all(raw[off + 2 * n:] == -777.0)
