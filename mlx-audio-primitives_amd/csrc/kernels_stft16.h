@@ -208,6 +208,27 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         int sq = sq0, sf = sf0;
         AP_PIN(sq);
         AP_PIN(sf);
+        // ALIGNED = 0: phi(bin) = frames from t0 to row `bin`'s next 128-byte boundary = -(a0 + bin Ts) mod 16.  The rows
+        // a thread owns are the bins 64 c + l and 1024 - 64 c - l with l = sq or sq + 32, and 64 Ts, 32 Ts and 1024 Ts
+        // are multiples of 16: phi takes THREE values per thread and group (k = 0: -(a0 + sq Ts), k = 1: -(a0 - sq Ts),
+        // k = 2: bin 512, -a0), and with it the staging column to read, whether the position is stored from the carry,
+        // where, and whether it is stored at all - once per group instead of once per element (the per-element form
+        // was 310 of this kernel's 810 VALU instructions per frame).
+        int k_rd[3];
+        bool k_take[3], k_store[3], k_flush[3];
+        ap_float2 *k_ob[3];
+        if (!ALIGNED) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ph = (0 - (a0 + (k == 0 ? sq * Ts15 : k == 1 ? -sq * Ts15 : 0))) & 15;
+                k_rd[k] = (sf + ph) & 15;
+                k_take[k] = sf < 16 - ph;
+                const int dt = ph + sf - 16;                       // frame t0 + dt of the row
+                k_store[k] = k_take[k] ? have_prev : dt < trem;
+                k_flush[k] = k_take[k] && ph + sf < trem;          // at a flush the carry just taken is frame t0 + dt + 16
+                k_ob[k] = ob + dt;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             ap_float2 *buf = OB + (c & 1) * (APS16_OB_ROWS * APS16_OB_ROW);
@@ -261,33 +282,32 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                     }
             } else {
                 // One LDS read per element: frame (sf + phi) mod 16 of this group is either stored now
-                // (sf >= 16 - phi) or becomes the carry while the old carry is stored.
-                int phi[5];
+                // (sf >= 16 - phi) or becomes the carry while the old carry is stored.  phi only depends on the
+                // element's class (cls[]: bins 64 c + l, bins 1024 - 64 c - l, bin 512 - see the group's head).
                 ap_float2 x[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
                     if (i < ne) {                                  // all LDS reads of the chunk first
-                        phi[i] = (0 - (a0 + bins[i] * Ts15)) & 15;
-                        x[i] = buf[slots[i] * APS16_OB_ROW + ((sf + phi[i]) & 15)];
+                        const int k = i == 4 ? 2 : (i >> 1);
+                        x[i] = buf[slots[i] * APS16_OB_ROW + k_rd[k]];
                     }
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
                     if (i < ne) {
+                        const int k = i == 4 ? 2 : (i >> 1);
                         ap_float2 &cy = i < 4 ? carry[c][i] : carry_mid;
                         const bool mine = i < 4 || tid < APS16_G;
-                        const bool take = sf < 16 - phi[i];
-                        const int dt = phi[i] + sf - 16;           // frame t0 + dt of the row
-                        const ap_float2 val = take ? cy : x[i];
-                        if (mine && (take ? have_prev : dt < trem)) AP_STORE2(&ob[bins[i] * Ts + dt], val, NT);
-                        if (take) cy = x[i];
+                        const ap_float2 val = k_take[k] ? cy : x[i];
+                        if (mine && k_store[k]) AP_STORE2(&k_ob[k][bins[i] * Ts], val, NT);
+                        if (k_take[k]) cy = x[i];
                     }
                 if (last) {                                        // flush: the carries just taken
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
                         if (i < ne) {
+                            const int k = i == 4 ? 2 : (i >> 1);
                             const bool mine = i < 4 || tid < APS16_G;
-                            if (mine && sf < 16 - phi[i] && phi[i] + sf < trem)
-                                AP_STORE2(&ob[bins[i] * Ts + phi[i] + sf], x[i], NT);
+                            if (mine && k_flush[k]) AP_STORE2(&k_ob[k][bins[i] * Ts + 16], x[i], NT);
                         }
                 }
             }

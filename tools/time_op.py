@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mlx_audio_primitives_amd as ap
 op = sys.argv[1]
+if op in ("stftd", "istftd"):          # the dense-row layout the C entry points ap_stft_f32 / ap_istft_f32 serve
+    ap.set_spectrum_layout("dense")
+    op = op[:-1]
 g = torch.Generator(device="cuda").manual_seed(1)
 L = 160000 if op == "whisper" else 220500
 ys = [torch.randn((256, L), device="cuda", generator=g) * 0.1 for _ in range(3)]
