@@ -396,7 +396,7 @@ ap_resample_decim_kernel(const float *x, int64_t L, int down, const float *taps,
         acc23[q] = ap_mk(0.0f, 0.0f);
         xq[q] = reinterpret_cast<const ap_rsp_f4 *>(xs + (AP_BLOCK * R * q + R * tid) * down);
     }
-#pragma unroll (STEPS > 0 ? STEPS / 4 : 1)
+#pragma clang loop unroll_count(STEPS > 0 ? STEPS / 4 : 1)
     for (int d = 0; d < steps; d += 4) {
         const ap_rsp_f4 h0 = hs4[d], h1 = hs4[d + 1], h2 = hs4[d + 2], h3 = hs4[d + 3];
 #pragma unroll
