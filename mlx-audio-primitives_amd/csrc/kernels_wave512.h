@@ -471,6 +471,19 @@ __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(Ap
         ap_float2 xk[4], xm[4], z256;
         aph_split<true>(v, X, tws0h, lane, xk, xm, z256);
 
+        int k_rd[3];
+        bool k_take[3], k_store[3], k_flush[3];
+        ap_float2 *k_ob[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int ph = (0 - (a0 + (k == 0 ? sq * T7 : k == 1 ? -sq * T7 : 0))) & 7;
+            k_rd[k] = (sf + ph) & 7;
+            k_take[k] = sf < 8 - ph;
+            const int dt = ph + sf - 8;
+            k_store[k] = k_take[k] ? have_prev : dt < trem;
+            k_flush[k] = k_take[k] && ph + sf < trem;
+            k_ob[k] = ob + dt;
+        }
         // ---- transposed store: chunk c holds r = 2c, 2c+1 (bins 64 r + lane and 512 - 64 r - lane) ----
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -484,7 +497,7 @@ __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(Ap
             }
             if (c == 1 && lane == 0) buf[256 * APHS_OB_ROW + wave] = ap_mk(z256.x, -z256.y);   // X[256] = conj Z[256]
             AP_LDS_BARRIER();
-            int bins[5], slots[5], phi[5];
+            int bins[5], slots[5];
             ap_float2 x[5];
             const int ne = c == 1 ? 5 : 4;
 #pragma unroll
@@ -495,29 +508,27 @@ __global__ void __launch_bounds__(64 * APHS_WAVES, 4) ap_stft1024_wave_kernel(Ap
             }
             bins[4] = APH_NC / 2;
             slots[4] = 256;
+            // phi(bin) = -(a0 + bin T) mod 8 only depends on the element's class (bins 64 r + sq: k = 0, bins
+            // 512 - 64 r - sq: k = 1, bin 256: k = 2; 64 T, 512 T and 256 T are multiples of 8): computed once per group
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (i < ne) x[i] = buf[slots[i] * APHS_OB_ROW + k_rd[i == 4 ? 2 : (i & 1)]];
 #pragma unroll
             for (int i = 0; i < 5; ++i)
                 if (i < ne) {
-                    phi[i] = (0 - (a0 + bins[i] * T7)) & 7;
-                    x[i] = buf[slots[i] * APHS_OB_ROW + ((sf + phi[i]) & 7)];
-                }
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-                if (i < ne) {
+                    const int k = i == 4 ? 2 : (i & 1);
                     ap_float2 &cy = i < 4 ? carry[c][i >> 1][i & 1] : carry_mid;
                     const bool mine = i < 4 || tid < APHS_WAVES;
-                    const bool take = sf < 8 - phi[i];
-                    const int dt = phi[i] + sf - 8;
-                    const ap_float2 val = take ? cy : x[i];
-                    if (mine && (take ? have_prev : dt < trem)) ob[bins[i] * Ti + dt] = val;
-                    if (take) cy = x[i];
+                    const ap_float2 val = k_take[k] ? cy : x[i];
+                    if (mine && k_store[k]) k_ob[k][bins[i] * Ti] = val;
+                    if (k_take[k]) cy = x[i];
                 }
             if (last) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
                     if (i < ne) {
                         const bool mine = i < 4 || tid < APHS_WAVES;
-                        if (mine && sf < 8 - phi[i] && phi[i] + sf < trem) ob[bins[i] * Ti + phi[i] + sf] = x[i];
+                        if (mine && k_flush[i == 4 ? 2 : (i & 1)]) k_ob[i == 4 ? 2 : (i & 1)][bins[i] * Ti + 8] = x[i];
                     }
             }
         }

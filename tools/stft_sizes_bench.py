@@ -3,7 +3,13 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mlx_audio_primitives_amd as ap
-from tools.bench_configs import timeit
+from tools.bench_configs import steady
+
+
+def timeit(fn, warm=0, reps=0):
+    return steady(lambda i: fn(), ramp_s=0.5)
+
+
 g = torch.Generator(device="cuda").manual_seed(1)
 y = torch.randn((256, 220500), device="cuda", generator=g) * 0.1
 out = {}

@@ -21,6 +21,8 @@ elif op == "mel512":
     fn, units = (lambda i: ap.melspectrogram(ys[i % 3], sr=22050, n_fft=512, hop_length=128, n_mels=64)), 256 * 1723
 elif op == "stft512":
     fn, units = (lambda i: ap.stft(ys[i % 3], n_fft=512, hop_length=128)), 256 * 1723
+elif op == "stft1024":
+    fn, units = (lambda i: ap.stft(ys[i % 3], n_fft=1024, hop_length=256)), 256 * 862
 elif op == "stftrows":      # n_fft = 2048 STFT into rows padded to whole 128-byte lines (Griffin-Lim workspace layout)
     import importlib
     stft_padded_rows = importlib.import_module("mlx_audio_primitives_amd.stft").stft_padded_rows
