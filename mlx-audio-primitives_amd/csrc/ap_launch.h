@@ -673,13 +673,18 @@ static inline int ap_prepare_stft16(ApStft16Params &W, const ApStftParams &P, in
     W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
     W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
     W.off_win = off; off += APW_NC * (int)sizeof(ap_float2);
-    W.off_ob = off; off += ap_align16(2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2));
+    *aligned = (Ts % APS16_G == 0 && (reinterpret_cast<uintptr_t>(P.out_c) & 127) == 0) ? 1 : 0;
+    // the line-padded layout's whole-group tile (T2): its rows 576 .. 1024 here, the others over the exchange buffers;
+    // otherwise two staging chunks
+    static_assert(APS16_T2_SPLIT * APS16_OB_ROW <= APS_WAVES * APW_X_COMPLEX, "tile rows over the exchange buffers");
+    const int ob_bytes = *aligned ? (1025 - APS16_T2_SPLIT) * APS16_OB_ROW * (int)sizeof(ap_float2)
+                                  : 2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2);
+    W.off_ob = off; off += ap_align16(ob_bytes);
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;
     if (Ts > (1 << 20)) return 1;                         // 32-bit row offsets (1024 Ts complex) in the store phase
     W.stagger = 0;
     W.gl_prev = nullptr; W.gl_mag = nullptr; W.gl_rebuilt = nullptr; W.gl_momentum = 0.0f;
-    *aligned = (Ts % APS16_G == 0 && (reinterpret_cast<uintptr_t>(P.out_c) & 127) == 0) ? 1 : 0;
     int64_t g = W.n_groups < 256 ? W.n_groups : 256;      // persistent: one workgroup per CU
     *grid = (int)g;
     return AP_OK;
@@ -690,7 +695,7 @@ static inline int ap_prepare_stft16(ApStft16Params &W, const ApStftParams &P, in
 static inline int ap_prepare_istft16(ApIstft16Params &W, const float *S, const float *tw, int64_t B, int64_t T,
                                      int64_t Ts, const float *window, int hop, int64_t out_offset, int64_t out_len,
                                      float *y, int *grid) {
-    if (B <= 0 || T <= 0 || Ts < T || Ts > (1 << 20)) return 1;       // 32-bit row offsets (1024 Ts complex)
+    if (B <= 0 || T <= 0 || Ts < T || Ts > 490000) return 1;          // a clip is one buffer resource: 1025 Ts 8 < 0xF0000000 bytes
     if (hop < 256 || hop > 1024 || 2048 % hop != 0) return 1;           // 256, 512, 1024 (hop = n_fft: the unfused kernels)
     if (out_offset % 4 != 0) return 1;
     W.S = reinterpret_cast<const ap_float2 *>(S);
@@ -705,11 +710,14 @@ static inline int ap_prepare_istft16(ApIstft16Params &W, const float *S, const f
     W.out_len = out_len;
     W.hop = hop;
     int off = APS_WAVES * APW_X_COMPLEX * (int)sizeof(ap_float2);
+    // the staging area follows the exchange buffers: the two-round staging pass runs its first 768 rows across both
+    static_assert(6 * 128 * APS16_OB_ROW <= APS_WAVES * APW_X_COMPLEX + 2 * APS16_OB_ROWS * APS16_OB_ROW, "round one of the tile");
+    static_assert(257 <= 2 * APS16_OB_ROWS, "round two of the tile");
+    W.off_ib = off; off += ap_align16(2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2));
     W.off_tw2 = off; off += APW_TW2_COMPLEX * (int)sizeof(ap_float2);
     W.off_tw1 = off; off += 16 * 64 * (int)sizeof(ap_float2);
     W.off_win = off; off += 2048 * (int)sizeof(float);
     W.off_inv = off; off += hop * (int)sizeof(float);
-    W.off_ib = off; off += ap_align16(2 * APS16_OB_ROWS * APS16_OB_ROW * (int)sizeof(ap_float2));
     W.off_carry = off; off += 2 * (2048 - hop) * (int)sizeof(float);
     W.lds_bytes = off;
     if (off > AP_LDS_MAX) return 1;

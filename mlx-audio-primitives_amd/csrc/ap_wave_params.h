@@ -66,7 +66,8 @@ struct ApStftWaveParams {
 // Every wave transforms TWO frames of a 16-frame group; rows of (B, F, T) leave as 128-byte windows.
 #define APS16_G 16           // frames per group = complex values per 128-byte row window
 #define APS16_OB_ROW 17      // complex slots per row of the transpose buffer (16 frames + 1 pad)
-#define APS16_OB_ROWS 129    // rows per chunk: 64 bins + 64 mirrored bins (+ bin 512 in the last chunk)
+#define APS16_OB_ROWS 129
+#define APS16_T2_SPLIT 576         // whole-group tile (T2): rows below live over the waves' exchange buffers, the other 449 beside them    // rows per chunk: 64 bins + 64 mirrored bins (+ bin 512 in the last chunk)
 
 struct ApStft16Params {
     const float *y;            // (B, L)

@@ -13,12 +13,17 @@
 // t0 + 8 + w kept in registers for the second step), and runs two 8-frame steps per load.
 #pragma once
 #include "kernels_wave.h"
+#include "ap_phase_clock.h"
 
 
 // HS = log2(hop): 8, 9 or 10 (the gather's loop bounds and shifts are compile-time constants)
 // TIGHT: the fenced, register-lean form of the transform (kernels_wave.h).  The unfenced one also fits (233 VGPRs, no
 // scratch) but measured 2.4 % slower here on the same box (0.3673 vs 0.3587 ms): AP_ISTFT16_LOOSE=1 selects it.
-template <int HS, bool TIGHT = true>
+// SPREAD: the next group's loads are issued from inside the first step's transform, two chunks at a time between its
+// stages, instead of in the staging pass.
+// TILE: the staging pass moves the group in two rounds (chunks 0..5 over the exchange buffers + the staging area, then
+// chunks 6, 7 and bin 512) with four barriers instead of eight rounds of one chunk.
+template <int HS, bool TIGHT = true, int SPREAD = 0, int TILE = 0>
 __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApIstft16Params P) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -38,6 +43,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     const int64_t h_lo = n_h * (int64_t)blockIdx.x / gridDim.x;
     const int64_t h_hi = n_h * ((int64_t)blockIdx.x + 1) / gridDim.x;
     if (h_lo >= h_hi) return;
+    AP_PH_DECL();
     // step h -> its 16-frame group (flattened over clips like P.n_g16) and its half
     auto group_of = [&](int64_t h) { const int64_t b = h / hpc; return b * P.g16_per_clip + ((h - b * hpc) >> 1); };
     const int64_t b_lo = h_lo / hpc;
@@ -48,21 +54,26 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     ap_float2 pre[8][4], pre_mid = ap_mk(0.0f, 0.0f);
     // (32-bit arithmetic: the launch code bounds Ts by 2^20, so bin Ts + t < 2^31)
     // chunk c of the 16-frame group g16 -> pre[c] (c == 7: + bin 512)
+    // The clip is a raw buffer resource: a load's address is base + lane offset (VGPR) + row offset (SGPR), so the 33
+    // loads of a group cost two lane offsets instead of 33 64-bit address computations (those were ~300 of the VALU
+    // instructions a wave spends per group, in a kernel whose transforms are VALU-bound), and a lane whose frame does
+    // not exist parks its offset out of range and reads zeros.  Mirrored rows count up from row 993 - 64 c - 32 j
+    // (lane part 31 - sq) so that no lane offset is negative.  The launch code bounds the clip by 0xF0000000 bytes.
+    const int64_t clip_bytes = (int64_t)F * P.Ts * (int64_t)sizeof(ap_float2);
     auto load_chunk = [&](int64_t g16, int c) {
-        int sq = sq0, sf = sf0;
-        AP_PIN(sq);                          // row offsets recomputed per use, not hoisted into 33 live registers
-        AP_PIN(sf);
         const int64_t b = g16 / P.g16_per_clip;
-        const int t = (int)((g16 - b * P.g16_per_clip) * APS16_G) + sf;
-        const ap_float2 *sb = P.S + b * (int64_t)F * P.Ts;
+        const int t = (int)((g16 - b * P.g16_per_clip) * APS16_G) + sf0;
+        const ApOutBuf sb = ap_outbuf_make(const_cast<char *>(reinterpret_cast<const char *>(P.S)) + b * clip_bytes, clip_bytes);
         const bool ok = t < Ti;
+        const unsigned lp = ok ? 8u * (unsigned)(sq0 * Ts + t) : 0xF0000000u;
+        const unsigned lm = ok ? 8u * (unsigned)((31 - sq0) * Ts + t) : 0xF0000000u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int l = sq + 32 * (i & 1);
-            const int bin = (i >> 1) ? APW_NC - 64 * c - l : 64 * c + l;
-            pre[c][i] = ok ? sb[bin * Ts + t] : ap_mk(0.0f, 0.0f);
+            const int j = i & 1;
+            pre[c][i] = (i >> 1) ? ap_outbuf_load2(sb, lm, 8u * (unsigned)((APW_NC - 31 - 64 * c - 32 * j) * Ts))
+                                 : ap_outbuf_load2(sb, lp, 8u * (unsigned)((64 * c + 32 * j) * Ts));
         }
-        if (c == 7 && tid < APS16_G) pre_mid = ok ? sb[(APW_NC / 2) * Ts + t] : ap_mk(0.0f, 0.0f);
+        if (c == 7) pre_mid = ap_outbuf_load2(sb, ok && tid < APS16_G ? 8u * (unsigned)t : 0xF0000000u, 8u * (unsigned)((APW_NC / 2) * Ts));
     };
     auto load16 = [&](int64_t g16) {
 #pragma unroll
@@ -103,6 +114,59 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     // workgroups (131 KB each) do not have to be served inside one gather.
     auto stage = [&](ap_float2 (&xkA)[8], ap_float2 (&xmA)[8], ap_float2 &xhA, ap_float2 (&xkB)[8], ap_float2 (&xmB)[8],
                      ap_float2 &xhB, int64_t next16) {
+        if constexpr (TILE != 0) {
+            // Two rounds.  The first one's 768 rows start at the exchange buffers (idle between the second step's gather
+            // and the merge: the barrier below) and run on into the staging area, which follows them in LDS; the second
+            // one's 257 rows are the staging area's alone, so the merge may start while other waves still read them.
+            ap_float2 *T1 = reinterpret_cast<ap_float2 *>(ap_smem);
+            ap_float2 *T2 = IB;
+            AP_LDS_BARRIER();                                            // every wave has left the gather
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    T1[(128 * c + (i >> 1) * 64 + sq0 + 32 * (i & 1)) * APS16_OB_ROW + sf0] = pre[c][i];
+            AP_PH(8);
+            AP_LDS_BARRIER();
+            AP_PH(9);
+            if (!SPREAD && next16 >= 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) load_chunk(next16, c);
+            }
+            AP_PH(10);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                xkA[c] = T1[(128 * c + lane) * APS16_OB_ROW + wave];
+                xkB[c] = T1[(128 * c + lane) * APS16_OB_ROW + 8 + wave];
+                xmA[c] = T1[(128 * c + 64 + lane) * APS16_OB_ROW + wave];
+                xmB[c] = T1[(128 * c + 64 + lane) * APS16_OB_ROW + 8 + wave];
+            }
+            AP_LDS_BARRIER();                                            // the staging area's first rows were round one's
+#pragma unroll
+            for (int c = 6; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    T2[(128 * (c - 6) + (i >> 1) * 64 + sq0 + 32 * (i & 1)) * APS16_OB_ROW + sf0] = pre[c][i];
+            if (tid < APS16_G) T2[256 * APS16_OB_ROW + sf0] = pre_mid;
+            AP_PH(8);
+            AP_LDS_BARRIER();
+            AP_PH(9);
+            if (!SPREAD && next16 >= 0) {
+                load_chunk(next16, 6);
+                load_chunk(next16, 7);
+            }
+            AP_PH(10);
+#pragma unroll
+            for (int c = 6; c < 8; ++c) {
+                xkA[c] = T2[(128 * (c - 6) + lane) * APS16_OB_ROW + wave];
+                xkB[c] = T2[(128 * (c - 6) + lane) * APS16_OB_ROW + 8 + wave];
+                xmA[c] = T2[(128 * (c - 6) + 64 + lane) * APS16_OB_ROW + wave];
+                xmB[c] = T2[(128 * (c - 6) + 64 + lane) * APS16_OB_ROW + 8 + wave];
+            }
+            xhA = T2[256 * APS16_OB_ROW + wave];
+            xhB = T2[256 * APS16_OB_ROW + 8 + wave];
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             ap_float2 *buf = IB + (c & 1) * (APS16_OB_ROWS * APS16_OB_ROW);
@@ -110,8 +174,11 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
             for (int i = 0; i < 4; ++i)
                 buf[((i >> 1) * 64 + sq0 + 32 * (i & 1)) * APS16_OB_ROW + sf0] = pre[c][i];
             if (c == 7 && tid < APS16_G) buf[128 * APS16_OB_ROW + sf0] = pre_mid;
+            AP_PH(8);
             AP_LDS_BARRIER();
-            if (next16 >= 0) load_chunk(next16, c);
+            AP_PH(9);
+            if (!SPREAD && next16 >= 0) load_chunk(next16, c);
+            AP_PH(10);
             xkA[c] = buf[lane * APS16_OB_ROW + wave];
             xkB[c] = buf[lane * APS16_OB_ROW + 8 + wave];
             xmA[c] = buf[(64 + lane) * APS16_OB_ROW + wave];
@@ -134,13 +201,22 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
 
     // One 8-frame step: frames t0 .. t0 + 7 of clip b from the waves' (xk, xm, xh); `half` picks the carry
     // buffers (steps alternate); `next16 >= 0`: issue the loads of that 16-frame group once xk / xm are consumed.
-    auto step = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 xh, int64_t b, int t0i, int half, bool emit) {
-        // ---- Hermitian merge: conj(Z[k]) / 2 and conj(Z[1024-k]) / 2 of the packed inverse -----
-        //   a = X[k] + conj X[1024-k], d = X[k] - conj X[1024-k], o = (W^-k / 2) d
-        //   conj Z[k] / 2 = conj(a/2 + i o),  conj Z[1024-k] / 2 = a/2 - i o
-        // the other waves may still be gathering the previous step's frames out of this wave's buffer (a
-        // first step is preceded by the barriers of the staging pass)
+    auto step = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 xh, int64_t b, int t0i, int half, bool emit,
+                    int64_t next16) {
+        // SPREAD: point pt = 0..3 of the group's first step (before the merge, before and after the transform, after the
+        // windowed frame is out) issues chunks 2 pt, 2 pt + 1 of the next group
+        auto issue = [&](int pt) __attribute__((always_inline)) {
+            if (SPREAD && next16 >= 0) {
+                AP_SCHED_FENCE();
+                load_chunk(next16, 2 * pt);
+                load_chunk(next16, 2 * pt + 1);
+                AP_SCHED_FENCE();
+            }
+        };
+        AP_PH(0);
         if (half) AP_LDS_BARRIER();
+        AP_PH(6);
+        issue(0);
         ap_float2 v[16];
         ap_float2 tws0h = lc.tws0h;          // opaque per step: keeps the 8 merge twiddles out of loop-invariant registers
         AP_PIN(tws0h.x);
@@ -164,8 +240,12 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         for (int j = 8; j < 16; ++j) v[j] = X[apw_zidx(lane + 64 * j)];
         AP_WAVE_SYNC();
         AP_SCHED_FENCE();
+        AP_PH(1);
+        issue(1);
         apw_forward<false, TIGHT>(v, X, TW1, lc);
         AP_SCHED_FENCE();
+        issue(2);
+        AP_PH(2);
         // ---- fused overlap-add ---------------------------------------------------------------
         float *carry_in = reinterpret_cast<float *>(ap_smem + P.off_carry) + half * CN;
         float *carry_out = reinterpret_cast<float *>(ap_smem + P.off_carry) + (half ^ 1) * CN;
@@ -182,7 +262,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         }
         if (t0i == 0)                                                // a clip starts: nothing carried in
             for (int i = tid; i < CN; i += 64 * APS_WAVES) carry_in[i] = 0.0f;
+        issue(3);
+        AP_PH(3);
         AP_LDS_BARRIER();
+        AP_PH(7);
         const bool clip_last = t0i + APS_WAVES >= Ti;
         const int64_t p0 = (int64_t)t0i * H;                         // padded position of r = 0
         float *yb = P.y + b * P.out_len;
@@ -252,9 +335,11 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
             if (n < 0) n = 0;
             for (n += tid; n < P.out_len; n += 64 * APS_WAVES) yb[n] = 0.0f;
         }
+        AP_PH(4);
     };
 
     ap_float2 xkA[8], xmA[8], xhA, xkB[8], xmB[8], xhB;
+    AP_PH(5);
     // A stretch that starts inside a clip first re-runs the 8 frames before it with the stores disabled: they
     // rebuild the carry (its length 2048 - hop is at most 7 frames for hop >= 256).
     if (warm_prev_group) {
@@ -262,7 +347,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         stage(xkA, xmA, xhA, xkB, xmB, xhB, group_of(h_lo));
         const int64_t b = gp / P.g16_per_clip;
         const int t0 = (int)((gp - b * P.g16_per_clip) * APS16_G);
-        step(xkB, xmB, xhB, b, t0 + 8, 1, false);
+        step(xkB, xmB, xhB, b, t0 + 8, 1, false, group_of(h_lo));
     }
     for (int64_t h = h_lo; h < h_hi;) {
         const int64_t b = h / hpc;
@@ -272,11 +357,13 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         const bool haveB = t0 + 8 < Ti;                              // the clip has frames in the group's second half
         const bool ownB = haveB && (startB || h + 1 < h_hi);
         const int64_t h_next = h + (startB ? 1 : (haveB ? 2 : 1));    // first step of the next group
-        stage(xkA, xmA, xhA, xkB, xmB, xhB, h_next < h_hi ? group_of(h_next) : -1);
-        step(xkA, xmA, xhA, b, t0, 0, !startB);                      // startB: the warm-up of the step this stretch starts with
+        const int64_t next16 = h_next < h_hi ? group_of(h_next) : -1;
+        stage(xkA, xmA, xhA, xkB, xmB, xhB, next16);
+        step(xkA, xmA, xhA, b, t0, 0, !startB, next16);                      // startB: the warm-up of the step this stretch starts with
         // (the carry parity continues either way: a clip that ends after a first step starts the next one with a
         //  zeroed carry_in of parity 0)
-        if (ownB) step(xkB, xmB, xhB, b, t0 + 8, 1, true);
+        if (ownB) step(xkB, xmB, xhB, b, t0 + 8, 1, true, -1);
         h = h_next;
     }
+    AP_PH_FLUSH();
 }

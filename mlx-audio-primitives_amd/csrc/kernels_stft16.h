@@ -23,6 +23,7 @@
 // of the Griffin-Lim loop): every group's segment is a whole line, no carries.
 #pragma once
 #include "kernels_wave.h"
+#include "ap_phase_clock.h"
 #include "kernels_pointwise.h"
 
 #ifdef AP_HOST_EMU
@@ -40,9 +41,21 @@
 // the group's first transform - they land under the two transforms - and then stores, per element, the raw bin
 // (next iteration's "previous") and   rebuilt = R' + m (R' - S unit(prev)),  R' = S unit(raw).
 // The separate projection pass over five (B, F, T) arrays and the re-read of the raw spectrum are gone.
-template <int PADGEN, int ALIGNED, int NT, int GL = 0>
+//
+// T2 = 1 (needs ALIGNED = 1, GL = 0; AP_STFT16_T2=1, NOT the default): the whole group is transposed at once - the
+// 16 x 1025 tile lives in LDS as a whole (rows 0..575 over the waves' exchange buffers, which are idle between two
+// groups' transforms, rows 576..1024 beside them), three LDS-only barriers per group instead of eight, every thread
+// ends up with its 33 elements in registers and stores them as one burst (buffer addressing: SGPR row offset + one lane
+// offset).  Measured round 3 with tools/phase_clock.py (profiles/README.md): the LDS phase does shrink from ~11 700 to
+// ~3 200 cycles per group, but a CU's one vector-memory pipe takes a store instruction per ~40 cycles and a load per
+// ~12, a wave blocks while its instructions wait to be taken, and 34 stores + 32 sample loads per thread in a row block
+// the waves for 12 000 - 20 000 cycles per group; in the eight-round form the same traffic drains between the rounds'
+// LDS latencies.  0.318 ms against 0.275 ms.  (Two more forms - the two waves of a SIMD storing at different times, and
+// the stores dribbled through the next group's transforms four at a time - were slower still, 0.39 and 0.31 ms.)
+template <int PADGEN, int ALIGNED, int NT, int GL = 0, int T2 = 0>
 __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApStft16Params P) {
     static_assert(!GL || ALIGNED, "the fused projection needs the line-padded layout");
+    static_assert(!T2 || (ALIGNED && !GL), "the whole-group tile is the line-padded layout's");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = AP_UNIFORM(tid >> 6);
@@ -51,9 +64,13 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     const ap_float2 *TW1 = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_tw1);
     const ap_float2 *WIN = reinterpret_cast<const ap_float2 *>(ap_smem + P.off_win);
     ap_float2 *OB = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);        // [2][129][17]
+    // E2 (with T2): both frames of a group are fetched ahead of the store burst of the group before (vector memory
+    // operations are taken in order by one pipe per CU: a load issued after the stores queues behind them)
+    constexpr bool E2 = T2 && !PADGEN;
     ap_float2 raw[16];
+    ap_float2 raw2[16];                 // T2: the group's second frame, fetched with the first one (before any store of the group before)
     // frame t0 + wave + 8 * second of the group
-    auto load_frame = [&](int64_t group, int second) {
+    auto load_frame_to = [&](ap_float2 (&raw)[16], int64_t group, int second) __attribute__((always_inline)) {
         const int64_t b = group / P.groups_per_clip;
         const int64_t t = (group - b * P.groups_per_clip) * APS16_G + wave + 8 * second;
         const float *yb = P.y + b * P.L;
@@ -62,6 +79,13 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         // frames beyond T read past the clip: zeros (never stored).  Edge / reflect padding only
         // touches the frames that overlap a clip boundary.
         const bool inside = !PADGEN || t >= P.T || (base >= 0 && base + 2 * APW_NC <= P.L);
+#ifdef AP_PHASE_CLOCK
+        if (P.stagger & 0x200) {                  // diagnostic knock-out: no sample loads
+#pragma unroll
+            for (int j = 0; j < 16; ++j) raw[j] = ap_mk((float)lane, (float)j);
+            return;
+        }
+#endif
         if (inside) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -78,7 +102,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     };
     const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
     const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
+    auto load_frame = [&](int64_t group, int second) __attribute__((always_inline)) { load_frame_to(raw, group, second); };
     if (!PADGEN && g_lo < g_hi) load_frame(g_lo, 0);        // the first frame's samples land under the table set-up
+    if (E2 && g_lo < g_hi) load_frame_to(raw2, g_lo, 1);
     apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
                     reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
                     reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid,
@@ -91,8 +117,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     // them with the same period: started together they also burst together, the memory system idles during the
     // transforms and the stores queue up behind each other during the bursts.  A start-up delay of a quarter
     // period per workgroup class spreads the bursts over the period.
-    for (int d = (int)((blockIdx.x >> 3) & 3) * P.stagger; d > 0; --d) __builtin_amdgcn_s_sleep(127);
+    for (int d = (int)((blockIdx.x >> 3) & 3) * (P.stagger & 0xFF); d > 0; --d) __builtin_amdgcn_s_sleep(127);
 #endif
+    AP_PH_DECL();
     const int F = APW_NC + 1;
     const int sq0 = tid >> 4, sf0 = tid & 15;                                // store role of this thread
     const int Ts = (int)P.Ts, Ts15 = (int)(P.Ts & 15);
@@ -103,8 +130,37 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
 #pragma unroll
             for (int i = 0; i < 4; ++i) carry[c][i] = ap_mk(0.0f, 0.0f);
     }
+    // T2: this thread's 33 elements of a group (rows sq0 / 32 + sq0 of bins 64 c + l and 1024 - 64 c - l, + bin 512)
+    ap_float2 r[8][4], r_mid = ap_mk(0.0f, 0.0f);
+    auto issue_stores = [&](int64_t grp) {
+        const int64_t gb = grp / P.groups_per_clip;
+        const int64_t gt0 = (grp - gb * P.groups_per_clip) * APS16_G;
+        const int64_t first = gb * (int64_t)F * P.Ts + gt0;       // out[gb, 0, gt0]; the resource ends with the clip's last row
+        const ApOutBuf od = ap_outbuf_make(P.out + first, ((int64_t)F * P.Ts - gt0) * (int64_t)sizeof(ap_float2));
+        const bool ok = sf0 < (int)(P.T - gt0);                    // the frame exists (lanes past the clip's end park)
+        const unsigned lp = ok ? 8u * (unsigned)(sq0 * Ts + sf0) : 0xF0000000u;
+        const unsigned lm = ok ? 8u * (unsigned)((31 - sq0) * Ts + sf0) : 0xF0000000u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = i & 1;
+                if (i >> 1) ap_outbuf_store2(od, lm, 8u * (unsigned)((APW_NC - 31 - 64 * c - 32 * j) * Ts), r[c][i]);
+                else ap_outbuf_store2(od, lp, 8u * (unsigned)((64 * c + 32 * j) * Ts), r[c][i]);
+            }
+        ap_outbuf_store2(od, ok && tid < APS16_G ? 8u * (unsigned)sf0 : 0xF0000000u, 8u * (unsigned)((APW_NC / 2) * Ts), r_mid);
+    };
+    // tile row rho = 128 c + 64 h + l (h = 0: bin 64 c + l, h = 1: bin 1024 - 64 c - l), rho = 1024: bin 512
+    ap_float2 *TR1 = reinterpret_cast<ap_float2 *>(ap_smem);               // rows 0 .. 575 (over the exchange buffers)
+    ap_float2 *TR2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_ob);    // rows 576 .. 1024
+    auto tile_row = [&](int c, int h, int l) -> ap_float2 * {             // c, h compile-time
+        const int rho = 128 * c + 64 * h;
+        return rho < APS16_T2_SPLIT ? TR1 + (rho + l) * APS16_OB_ROW : TR2 + (rho - APS16_T2_SPLIT + l) * APS16_OB_ROW;
+    };
+
     // windowed frame in raw[] -> xk[r] = X[lane + 64 r], xm[r] = X[1024 - lane - 64 r], zh = Z[512]
-    auto transform = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 &zh, int64_t next_group, int next_second) {
+    auto transform = [&](ap_float2 (&xk)[8], ap_float2 (&xm)[8], ap_float2 &zh, int64_t next_group, int next_second,
+                         ap_float2 (&raw)[16]) __attribute__((always_inline)) {
         ap_float2 v[16];
         AP_SCHED_FENCE();
         // window in four batches: the 16 table values never sit in registers together (this is where the
@@ -118,10 +174,13 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             for (int j = 0; j < 4; ++j) v[4 * q + j] = ap_mul2(raw[4 * q + j], w[j]);
             AP_SCHED_FENCE();
         }
+        AP_PH(0);
         if (!PADGEN && next_group >= 0) load_frame(next_group, next_second);   // lands under the transform
         AP_SCHED_FENCE();
+        AP_PH(1);
         apw_forward<true, (!ALIGNED || GL)>(v, X, TW1, lc);
         AP_SCHED_FENCE();
+        AP_PH(2);
         ApwLane ls = lc;
         if (!ALIGNED || GL) {                // keeps the 8 split twiddles from being hoisted out of the group loop
             AP_PIN(ls.tws0h.x);
@@ -129,6 +188,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         }
         apw_split<true>(X, ls, xk, xm, zh);
         AP_SCHED_FENCE();
+        AP_PH(3);
     };
 
     // every workgroup owns a contiguous stretch of the (clip, 16-frame group) stream: a row's
@@ -186,21 +246,61 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             if (tid < APS16_G) gpv_mid = ok ? pb[(APW_NC / 2) * Ts + sf] : ap_mk(0.0f, 0.0f);
         }
         if (PADGEN) load_frame(group, 0);
-        transform(xkA, xmA, zhA, group, 1);
+        transform(xkA, xmA, zhA, E2 ? -1 : group, 1, raw);
         if (GL) {                                  // the first four chunks' magnitudes land under the second transform
             AP_SCHED_FENCE();
             gl_load_mag(0, 4);
             AP_SCHED_FENCE();
         }
         if (PADGEN) load_frame(group, 1);
-        transform(xkB, xmB, zhB, -1, 0);
+        transform(xkB, xmB, zhB, -1, 0, E2 ? raw2 : raw);
         // the next group's first frame lands under the store phase (during the second transform the
         // registers hold the first frame's spectrum instead)
         AP_SCHED_FENCE();
         if (GL) gl_load_mag(4, 8);
         // (GL: the projection's operands fill the registers until half of the chunks are out: the prefetch waits)
-        if (!GL && !PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
+        if (!GL && !PADGEN && !T2 && group + 1 < g_hi) load_frame(group + 1, 0);
         AP_SCHED_FENCE();
+        AP_PH(4);
+
+        if constexpr (T2 != 0) {
+            AP_PH(8);
+            // the part of the tile beside the exchange buffers first; the rest once every wave has left its transform
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bool second = 128 * c + 64 * h >= APS16_T2_SPLIT;
+                        if (second != (pass == 0)) continue;
+                        ap_float2 *row = tile_row(c, h, lane);
+                        row[wave] = h ? xmA[c] : xkA[c];
+                        row[8 + wave] = h ? xmB[c] : xkB[c];
+                    }
+                if (pass == 0 && lane == 0) {                            // X[512] = conj Z[512]
+                    ap_float2 *row = TR2 + (1024 - APS16_T2_SPLIT) * APS16_OB_ROW;
+                    row[wave] = ap_mk(zhA.x, -zhA.y);
+                    row[8 + wave] = ap_mk(zhB.x, -zhB.y);
+                }
+                AP_LDS_BARRIER();
+            }
+            AP_PH(5);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[c][i] = tile_row(c, i >> 1, sq0 + 32 * (i & 1))[sf0];
+            r_mid = TR2[(1024 - APS16_T2_SPLIT) * APS16_OB_ROW + sf0];
+            AP_LDS_BARRIER();                                            // the exchange buffers are the waves' again
+            AP_PH(6);
+            if (!PADGEN && group + 1 < g_hi) {                      // into an idle pipe, ahead of the stores
+                load_frame(group + 1, 0);
+                load_frame_to(raw2, group + 1, 1);
+            }
+            issue_stores(group);
+            AP_PH(7);
+            continue;
+        }
 
         // ---- transposed store: chunk c holds bins 64 c + lane and 1024 - 64 c - lane ----------
         // (the thread's store role is made opaque per group: otherwise the compiler hoists the row
@@ -240,7 +340,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                 buf[128 * APS16_OB_ROW + wave] = ap_mk(zhA.x, -zhA.y);
                 buf[128 * APS16_OB_ROW + 8 + wave] = ap_mk(zhB.x, -zhB.y);
             }
+            AP_PH(5);
             AP_LDS_BARRIER();
+            AP_PH(6);
             if (GL && c == 4) {
                 AP_SCHED_FENCE();
                 if (!PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
@@ -267,6 +369,9 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                 for (int i = 0; i < 5; ++i)
                     if (i < ne) {
                         const bool mine = i < 4 || tid < APS16_G;
+#ifdef AP_PHASE_CLOCK
+                        if (P.stagger & 0x100) { if (x[i].x == 123.456f) ob[0] = x[i]; continue; }   // diagnostic knock-out: no stores
+#endif
                         if (mine && sf < trem) AP_STORE2(&ob[bins[i] * Ts + sf], x[i], NT);
                         if (GL && mine && sf < trem) {
                             // the arithmetic of ap_gl_rows_kernel (kernels_pointwise.h), operation for operation
@@ -311,8 +416,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                         }
                 }
             }
+            AP_PH(7);
         }
     }
+    AP_PH_FLUSH();
 }
 
 // (Round 3 also measured a software-pipelined form of the ALIGNED kernel: the transform cut at its two wave-private LDS

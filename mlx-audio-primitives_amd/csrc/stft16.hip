@@ -8,10 +8,14 @@
 
 thread_local int ap_g16_grid_cap = 0;
 
-template <int PADGEN, int ALIGNED, int NT, int GL = 0>
+template <int PADGEN, int ALIGNED, int NT, int GL = 0, int T2 = 0>
 static int ap_stft16_go(const ApStft16Params &W, int grid, void *stream) {
     if (ap_g16_grid_cap > 0 && grid > ap_g16_grid_cap) grid = ap_g16_grid_cap;
-    auto kern = ap_stft2048_g16_kernel<PADGEN, ALIGNED, NT, GL>;
+#ifdef AP_PHASE_CLOCK
+    static const int diag_cap = std::getenv("AP_G16_GRID_CAP") ? std::atoi(std::getenv("AP_G16_GRID_CAP")) : 0;   // diagnostic build only
+    if (diag_cap > 0 && grid > diag_cap) grid = diag_cap;
+#endif
+    auto kern = ap_stft2048_g16_kernel<PADGEN, ALIGNED, NT, GL, T2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, W.lds_bytes);
     if (e != hipSuccess) AP_FAIL(AP_ERR_HIP, "hipFuncSetAttribute(LDS=%d): %s", W.lds_bytes, hipGetErrorString(e));
@@ -33,6 +37,10 @@ int ap_launch_stft16(const ApStftParams &P, int64_t B, int64_t Ts, void *stream)
     static const int stagger = std::getenv("AP_STFT16_STAGGER") ? std::atoi(std::getenv("AP_STFT16_STAGGER")) : 0;
     W.stagger = stagger;
     const bool pg = !ap_clip_loads_ok(W);
+    // A/B switch: AP_STFT16_T2=1 the whole-group tile (kernels_stft16.h; measured slower, not the default)
+    static const int t2 = std::getenv("AP_STFT16_T2") ? std::atoi(std::getenv("AP_STFT16_T2")) : 0;
+    if (aligned && t2 == 1 && Ts <= 490000) return pg   // (a clip is one buffer resource there: 1025 Ts 8 < 0xF0000000 bytes)
+        ? ap_stft16_go<1, 1, 0, 0, 1>(W, grid, stream) : ap_stft16_go<0, 1, 0, 0, 1>(W, grid, stream);
     if (aligned) {
         if (pg) return nt ? ap_stft16_go<1, 1, 1>(W, grid, stream) : ap_stft16_go<1, 1, 0>(W, grid, stream);
         return nt ? ap_stft16_go<0, 1, 1>(W, grid, stream) : ap_stft16_go<0, 1, 0>(W, grid, stream);
@@ -56,3 +64,11 @@ int ap_launch_stft16_gl(const ApStftParams &P, int64_t B, int64_t Ts, const floa
     if (!ap_clip_loads_ok(W)) return ap_stft16_go<1, 1, 0, 1>(W, grid, stream);
     return ap_stft16_go<0, 1, 0, 1>(W, grid, stream);
 }
+
+#ifdef AP_PHASE_CLOCK
+// diagnostic build only (tools/phase_clock.py)
+extern "C" int ap_phase_read_stft16(unsigned long long *host, int n_words) {
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(ap_phase_clk), sizeof(unsigned long long) * (size_t)n_words);
+    return e == hipSuccess ? 0 : 1;
+}
+#endif

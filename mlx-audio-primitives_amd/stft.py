@@ -161,7 +161,7 @@ def stft(y, n_fft: int = 2048, hop_length: int | None = None, win_length: int | 
     F = n_fft // 2 + 1
     Ts = T
     if n_fft in _LINES_N_FFT and _SPECTRUM_LAYOUT == "lines" and T % 16 and B > 0 and L > 0 and B * T >= 512 \
-            and T < (1 << 19) - 16:
+            and T < 490000 - 16:          # (the n_fft = 2048 ISTFT addresses a clip as one buffer resource: 1025 Ts 8 < 0xF0000000 bytes)
         Ts = -(-T // 16) * 16                # rows padded to whole 128-byte lines (see _SPECTRUM_LAYOUT)
     out = torch.empty((B, F, Ts, 2), dtype=torch.float32, device=dev)
     if B > 0 and L > 0:

@@ -295,7 +295,7 @@ def istft_fused(S, hop, window, out_len, out_offset=None, grid_cap=0):
     return out
 
 
-def istft16(S, hop, window, out_len, out_offset=1024, grid_cap=0, Ts=None):
+def istft16(S, hop, window, out_len, out_offset=1024, grid_cap=0, Ts=None, variant=0):
     """kernels_istft16.h: fused ISTFT of an n_fft = 2048 (B, 1025, T) spectrum held with rows Ts apart."""
     S = np.ascontiguousarray(S, np.complex64)
     B, F, T = S.shape
@@ -308,7 +308,7 @@ def istft16(S, hop, window, out_len, out_offset=1024, grid_cap=0, Ts=None):
     window = np.ascontiguousarray(window, np.float32)
     tw = twiddles(2048)
     _check(lib().emu_istft16_f32(_p(Sv), _i64(B), _i64(T), _i64(Ts), hop, _p(window), _p(tw), _i64(out_offset),
-                                 _i64(out_len), grid_cap, _p(out)))
+                                 _i64(out_len), grid_cap, variant, _p(out)))
     return out
 
 

@@ -178,7 +178,11 @@ int emu_stft16_f32(const float *y, int64_t B, int64_t L, int hop, const float *w
     if (grid > grid_cap) grid = grid_cap;   // exercise the persistent group loop and the carries
     const bool pg = !ap_clip_loads_ok(W);
     emu_lds_limit(W.lds_bytes);
-    if (aligned) {
+    // force_unaligned: 1 = the carry path on an aligned layout; 3 = the whole-group tile (T2 = 1)
+    if (aligned && force_unaligned == 3) {
+        if (pg) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<1, 1, 0, 0, 1>(W); });
+        else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<0, 1, 0, 0, 1>(W); });
+    } else if (aligned) {
         if (pg) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<1, 1, 0>(W); });
         else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<0, 1, 0>(W); });
     } else {
@@ -439,7 +443,7 @@ int emu_istft_fused_f32(const float *S, int64_t B, int64_t T, int hop, const flo
 
 // n_fft = 2048 fused ISTFT with 16-frame loads (kernels_istft16.h); S has rows Ts complex apart
 int emu_istft16_f32(const float *S, int64_t B, int64_t T, int64_t Ts, int hop, const float *window, const float *tw,
-                    int64_t out_offset, int64_t out_len, int grid_cap, float *out) {
+                    int64_t out_offset, int64_t out_len, int grid_cap, int variant, float *out) {
     ApIstft16Params W;
     int grid = 0;
     if (ap_prepare_istft16(W, S, tw, B, T, Ts, window, hop, out_offset, out_len, out, &grid) != AP_OK)
@@ -447,9 +451,17 @@ int emu_istft16_f32(const float *S, int64_t B, int64_t T, int64_t Ts, int hop, c
     const int64_t n_steps = ((T + 7) / 8) * B;                // the kernel's stretches are in 8-frame steps
     if (grid_cap > 0) grid = grid_cap < n_steps ? grid_cap : (int)n_steps;
     emu_lds_limit(W.lds_bytes);
-    if (hop == 256) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<8>(W); });
-    else if (hop == 512) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<9>(W); });
-    else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<10>(W); });
+    // variant 0: the product's default (two-round staging pass, the next group's loads issued inside the first step's
+    // transform); 1: eight rounds; 2 / 3: the same two with the loads issued in the staging pass
+#define EMU_ISTFT16(SP, TL) do { \
+    if (hop == 256) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<8, true, SP, TL>(W); }); \
+    else if (hop == 512) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<9, true, SP, TL>(W); }); \
+    else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_istft2048_g16_kernel<10, true, SP, TL>(W); }); } while (0)
+    if (variant == 0) EMU_ISTFT16(1, 1);
+    else if (variant == 1) EMU_ISTFT16(1, 0);
+    else if (variant == 2) EMU_ISTFT16(0, 1);
+    else EMU_ISTFT16(0, 0);
+#undef EMU_ISTFT16
     return AP_OK;
 }
 

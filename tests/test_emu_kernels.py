@@ -72,6 +72,10 @@ def test_emu_stft(n_fft, hop, L, B, pad_mode, center):
     (512, 20000, 2, "constant", True, 48, 6, 0, False),
     (512, 60000, 1, "constant", False, 128, 1, 0, False),
     (255, 9000, 2, "constant", True, 48, 2, 0, False),
+    # padded rows on the whole-group tile (3; AP_STFT16_T2=1)
+    (512, 20000, 2, "edge", True, 48, 3, 0, 3),
+    (512, 60000, 1, "constant", False, 128, 1, 0, 3),
+    (512, 10752, 3, "constant", True, 32, 2, 0, 3),
 ])
 def test_emu_stft16(hop, L, B, pad_mode, center, Ts, grid_cap, misalign, force_unaligned):
     """kernels_stft16.h (n_fft = 2048, 16 frames per group, 128-byte row windows) on the CPU."""
@@ -84,7 +88,7 @@ def test_emu_stft16(hop, L, B, pad_mode, center, Ts, grid_cap, misalign, force_u
     np.testing.assert_allclose(S, R, rtol=1e-4, atol=1e-4)
     T = R.shape[-1]
     Tr = T if Ts is None else Ts
-    assert aligned == int(Tr % 16 == 0 and misalign == 0 and force_unaligned != True)
+    assert aligned == int(Tr % 16 == 0 and misalign == 0 and force_unaligned != 1)
     # nothing outside the T frames of every row was touched (row padding, guard floats either side)
     n = B * 1025 * Tr
     assert np.all(raw[:off] == -777.0) and np.all(raw[off + 2 * n:] == -777.0)
@@ -232,32 +236,38 @@ def test_emu_istft_fused(hop, L, B, grid_cap):
         np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=2048, length=length), atol=1e-5)
 
 
-@pytest.mark.parametrize("hop,L,B,grid_cap,Ts", [
-    (512, 10752, 3, 2, None),       # T = 22: two 16-frame groups per clip, the second with 6 frames; clip change in a stretch
-    (512, 20000, 2, 5, None),       # T = 40: stretches that start inside a clip (8-frame warm-up step)
-    (512, 20000, 2, 3, 48),         # padded rows (whole 128-byte lines); 10 steps on 3 workgroups: a stretch starts on a second step
-    (512, 20000, 2, 7, None),       # 10 steps on 7 workgroups: one- and two-step stretches, odd and even starts
-    (512, 20000, 2, 10, None),      # one step per workgroup
-    (512, 11300, 2, 1, None),       # T = 23: second step with 7 frames
-    (512, 12400, 2, 4, 30),         # T = 25: the clip ends after a first step (one frame in the last group)
-    (1024, 30000, 2, 2, None),
-    (256, 9000, 1, 2, None),
-    (512, 6000, 1, 0, None),
+@pytest.mark.parametrize("hop,L,B,grid_cap,Ts,variant", [
+    (512, 10752, 3, 2, None, 0),    # T = 22: two 16-frame groups per clip, the second with 6 frames; clip change in a stretch
+    (512, 20000, 2, 5, None, 0),    # T = 40: stretches that start inside a clip (8-frame warm-up step)
+    (512, 20000, 2, 3, 48, 0),      # padded rows (whole 128-byte lines); 10 steps on 3 workgroups: a stretch starts on a second step
+    (512, 20000, 2, 7, None, 0),    # 10 steps on 7 workgroups: one- and two-step stretches, odd and even starts
+    (512, 20000, 2, 10, None, 0),   # one step per workgroup
+    (512, 11300, 2, 1, None, 0),    # T = 23: second step with 7 frames
+    (512, 12400, 2, 4, 30, 0),      # T = 25: the clip ends after a first step (one frame in the last group)
+    (1024, 30000, 2, 2, None, 0),
+    (256, 9000, 1, 2, None, 0),
+    (512, 6000, 1, 0, None, 0),
+    # the eight-round staging pass (1) and the loads issued in the staging pass (2, 3)
+    (512, 20000, 2, 3, 48, 1),
+    (512, 20000, 2, 7, None, 1),
+    (512, 20000, 2, 5, None, 2),
+    (512, 12400, 2, 4, 30, 2),
+    (256, 9000, 1, 2, None, 3),
 ])
-def test_emu_istft16(hop, L, B, grid_cap, Ts):
+def test_emu_istft16(hop, L, B, grid_cap, Ts, variant):
     """kernels_istft16.h: 16-frame loads as they fall, two 8-frame overlap-add steps per load."""
     rng = np.random.default_rng(hop + L)
     y = rng.standard_normal((B, L)).astype(np.float32)
     S = ao.stft(y, n_fft=2048, hop_length=hop)
     win = ao.padded_window("hann", 2048, 2048)
     for length in (L, L - 700):
-        out = eb.istft16(S, hop, win, length, grid_cap=grid_cap, Ts=Ts)
+        out = eb.istft16(S, hop, win, length, grid_cap=grid_cap, Ts=Ts, variant=variant)
         np.testing.assert_allclose(out, ao.istft(S, hop_length=hop, n_fft=2048, length=length), atol=1e-5)
     # center=False: no trim, output longer than the frames reach (zero tail)
     # (where the window sum of squares is tiny - the first and last samples of a clip without centring - float32
     #  rounding of the frames is amplified by up to 1e8: compare where the divisor is not)
     n = L + 2048 + 100
-    out = eb.istft16(S, hop, win, n, out_offset=0, grid_cap=grid_cap, Ts=Ts)
+    out = eb.istft16(S, hop, win, n, out_offset=0, grid_cap=grid_cap, Ts=Ts, variant=variant)
     ref = ao.istft(S, hop_length=hop, n_fft=2048, center=False, length=n)
     wss = np.zeros(n + 2048)
     for t in range(S.shape[-1]):
