@@ -44,8 +44,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     const int64_t h_hi = n_h * ((int64_t)blockIdx.x + 1) / gridDim.x;
     if (h_lo >= h_hi) return;
     AP_PH_DECL();
-    // step h -> its 16-frame group (flattened over clips like P.n_g16) and its half
-    auto group_of = [&](int64_t h) { const int64_t b = h / hpc; return b * P.g16_per_clip + ((h - b * hpc) >> 1); };
+    // A 16-frame group travels as one word, (clip << 32) | first frame, -1 = none; the loop below steps (clip, step in
+    // clip) along instead of dividing (a 64-bit division by a run-time divisor is ~100 scalar instructions, and the
+    // loaders used to make one per chunk)
+    auto group_code = [](int64_t b, int t0) { return (b << 32) | (int64_t)(uint32_t)t0; };
     const int64_t b_lo = h_lo / hpc;
     const int hc_lo = (int)(h_lo - b_lo * hpc);                                  // first step's index in its clip
     // loader role: thread (sq = tid / 16, sf = tid % 16) fetches frame t0 + sf of the rows sq, 32 + sq (bins
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     // (lane part 31 - sq) so that no lane offset is negative.  The launch code bounds the clip by 0xF0000000 bytes.
     const int64_t clip_bytes = (int64_t)F * P.Ts * (int64_t)sizeof(ap_float2);
     auto load_chunk = [&](int64_t g16, int c) {
-        const int64_t b = g16 / P.g16_per_clip;
-        const int t = (int)((g16 - b * P.g16_per_clip) * APS16_G) + sf0;
+        const int64_t b = AP_UNIFORM((int)(g16 >> 32));           // (explicitly uniform: the clip's buffer resource is scalar)
+        const int t = AP_UNIFORM((int)(uint32_t)g16) + sf0;
         const ApOutBuf sb = ap_outbuf_make(const_cast<char *>(reinterpret_cast<const char *>(P.S)) + b * clip_bytes, clip_bytes);
         const bool ok = t < Ti;
         const unsigned lp = ok ? 8u * (unsigned)(sq0 * Ts + t) : 0xF0000000u;
@@ -83,7 +85,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     // an even first step inside a clip is preceded by the second step of the group before it (other loads); an odd
     // one by the first step of its own group
     const bool warm_prev_group = hc_lo > 0 && !(hc_lo & 1);
-    load16(warm_prev_group ? group_of(h_lo) - 1 : group_of(h_lo));
+    const int64_t g_first = group_code(b_lo, (hc_lo >> 1) * APS16_G);
+    load16(warm_prev_group ? group_code(b_lo, ((hc_lo >> 1) - 1) * APS16_G) : g_first);
     {
         ap_float2 *tw2 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2);
         ap_float2 *tw1 = reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1);
@@ -343,27 +346,30 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
     // A stretch that starts inside a clip first re-runs the 8 frames before it with the stores disabled: they
     // rebuild the carry (its length 2048 - hop is at most 7 frames for hop >= 256).
     if (warm_prev_group) {
-        const int64_t gp = group_of(h_lo) - 1;
-        stage(xkA, xmA, xhA, xkB, xmB, xhB, group_of(h_lo));
-        const int64_t b = gp / P.g16_per_clip;
-        const int t0 = (int)((gp - b * P.g16_per_clip) * APS16_G);
-        step(xkB, xmB, xhB, b, t0 + 8, 1, false, group_of(h_lo));
+        stage(xkA, xmA, xhA, xkB, xmB, xhB, g_first);
+        step(xkB, xmB, xhB, b_lo, ((hc_lo >> 1) - 1) * APS16_G + 8, 1, false, g_first);
     }
+    int64_t b = b_lo;
+    int hc = hc_lo;
     for (int64_t h = h_lo; h < h_hi;) {
-        const int64_t b = h / hpc;
-        const int hc = (int)(h - b * hpc);
         const int t0 = (hc >> 1) * APS16_G;
         const bool startB = hc & 1;                                  // only the stretch's first step can be odd
         const bool haveB = t0 + 8 < Ti;                              // the clip has frames in the group's second half
         const bool ownB = haveB && (startB || h + 1 < h_hi);
-        const int64_t h_next = h + (startB ? 1 : (haveB ? 2 : 1));    // first step of the next group
-        const int64_t next16 = h_next < h_hi ? group_of(h_next) : -1;
+        const int adv = startB ? 1 : (haveB ? 2 : 1);                // to the first step of the next group
+        const int64_t h_next = h + adv;
+        int hc_n = hc + adv;
+        int64_t b_n = b;
+        if (hc_n >= (int)hpc) { hc_n = 0; ++b_n; }
+        const int64_t next16 = h_next < h_hi ? group_code(b_n, (hc_n >> 1) * APS16_G) : -1;
         stage(xkA, xmA, xhA, xkB, xmB, xhB, next16);
-        step(xkA, xmA, xhA, b, t0, 0, !startB, next16);                      // startB: the warm-up of the step this stretch starts with
+        step(xkA, xmA, xhA, b, t0, 0, !startB, next16);               // startB: the warm-up of the step this stretch starts with
         // (the carry parity continues either way: a clip that ends after a first step starts the next one with a
         //  zeroed carry_in of parity 0)
         if (ownB) step(xkB, xmB, xhB, b, t0 + 8, 1, true, -1);
         h = h_next;
+        b = b_n;
+        hc = hc_n;
     }
     AP_PH_FLUSH();
 }

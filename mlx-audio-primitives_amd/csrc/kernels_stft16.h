@@ -71,8 +71,11 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     ap_float2 raw2[16];                 // T2: the group's second frame, fetched with the first one (before any store of the group before)
     // frame t0 + wave + 8 * second of the group
     auto load_frame_to = [&](ap_float2 (&raw)[16], int64_t group, int second) __attribute__((always_inline)) {
-        const int64_t b = group / P.groups_per_clip;
-        const int64_t t = (group - b * P.groups_per_clip) * APS16_G + wave + 8 * second;
+        // (a group travels as (clip << 32) | first frame: the loop steps both along, no division per use)
+        // (made uniform explicitly: the compiler does not see it through the packed word and builds the clip's buffer
+        //  resource in a waterfall loop otherwise)
+        const int64_t b = AP_UNIFORM((int)(group >> 32));
+        const int64_t t = (int64_t)AP_UNIFORM((int)(uint32_t)group) + wave + 8 * second;
         const float *yb = P.y + b * P.L;
         const ApClip clip = ap_clip_make(yb, P.L);
         const int64_t base = t * (int64_t)P.hop - P.pad;          // wave-uniform
@@ -103,8 +106,12 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     const int64_t g_lo = P.n_groups * (int64_t)blockIdx.x / gridDim.x;
     const int64_t g_hi = P.n_groups * ((int64_t)blockIdx.x + 1) / gridDim.x;
     auto load_frame = [&](int64_t group, int second) __attribute__((always_inline)) { load_frame_to(raw, group, second); };
-    if (!PADGEN && g_lo < g_hi) load_frame(g_lo, 0);        // the first frame's samples land under the table set-up
-    if (E2 && g_lo < g_hi) load_frame_to(raw2, g_lo, 1);
+    auto group_code = [](int64_t b, int64_t t0) { return (b << 32) | t0; };
+    const int gpc = (int)P.groups_per_clip;
+    int64_t b_cur = g_lo / P.groups_per_clip;                        // the stretch's first group: clip and index in the clip
+    int gi_cur = (int)(g_lo - b_cur * P.groups_per_clip);
+    if (!PADGEN && g_lo < g_hi) load_frame(group_code(b_cur, gi_cur * APS16_G), 0);        // the first frame's samples land under the table set-up
+    if (E2 && g_lo < g_hi) load_frame_to(raw2, group_code(b_cur, gi_cur * APS16_G), 1);
     apw_fill_tables(reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw2),
                     reinterpret_cast<ap_float2 *>(ap_smem + P.off_tw1),
                     reinterpret_cast<ap_float2 *>(ap_smem + P.off_win), P.tw, P.window, tid,
@@ -133,8 +140,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     // T2: this thread's 33 elements of a group (rows sq0 / 32 + sq0 of bins 64 c + l and 1024 - 64 c - l, + bin 512)
     ap_float2 r[8][4], r_mid = ap_mk(0.0f, 0.0f);
     auto issue_stores = [&](int64_t grp) {
-        const int64_t gb = grp / P.groups_per_clip;
-        const int64_t gt0 = (grp - gb * P.groups_per_clip) * APS16_G;
+        const int64_t gb = AP_UNIFORM((int)(grp >> 32));
+        const int64_t gt0 = AP_UNIFORM((int)(uint32_t)grp);
         const int64_t first = gb * (int64_t)F * P.Ts + gt0;       // out[gb, 0, gt0]; the resource ends with the clip's last row
         const ApOutBuf od = ap_outbuf_make(P.out + first, ((int64_t)F * P.Ts - gt0) * (int64_t)sizeof(ap_float2));
         const bool ok = sf0 < (int)(P.T - gt0);                    // the frame exists (lanes past the clip's end park)
@@ -195,9 +202,12 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
     // window is completed one group later by the same thread (ALIGNED = 0), and the lines of
     // consecutive groups follow each other from the same CU
 
-    for (int64_t group = g_lo; group < g_hi; ++group) {
-        const int64_t b = group / P.groups_per_clip;
-        const int64_t t0 = (group - b * P.groups_per_clip) * APS16_G;
+    for (int64_t group = g_lo; group < g_hi; ++group, b_cur = gi_cur + 1 >= gpc ? b_cur + 1 : b_cur, gi_cur = gi_cur + 1 >= gpc ? 0 : gi_cur + 1) {
+        // (GL = 1 sits at 256 registers: the stepped form cost it 8 spilled ones, so it keeps the division)
+        const int64_t b = GL ? group / P.groups_per_clip : b_cur;
+        const int64_t t0 = GL ? (group - b * P.groups_per_clip) * APS16_G : (int64_t)gi_cur * APS16_G;
+        const int64_t gc = group_code(b, t0);                                       // this group and the next one
+        const int64_t gc_n = t0 + APS16_G >= (int64_t)gpc * APS16_G ? group_code(b + 1, 0) : group_code(b, t0 + APS16_G);
         ap_float2 *ob = P.out + b * (int64_t)F * P.Ts + t0;
         // (complex index of out[b, 0, t0]) mod 16: the same for every group of a clip
         const int a0 = (int)(((reinterpret_cast<uintptr_t>(P.out) >> 3) + (uint64_t)(b * (int64_t)F * P.Ts + t0)) & 15);
@@ -245,21 +255,21 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                 }
             if (tid < APS16_G) gpv_mid = ok ? pb[(APW_NC / 2) * Ts + sf] : ap_mk(0.0f, 0.0f);
         }
-        if (PADGEN) load_frame(group, 0);
-        transform(xkA, xmA, zhA, E2 ? -1 : group, 1, raw);
+        if (PADGEN) load_frame(gc, 0);
+        transform(xkA, xmA, zhA, E2 ? -1 : gc, 1, raw);
         if (GL) {                                  // the first four chunks' magnitudes land under the second transform
             AP_SCHED_FENCE();
             gl_load_mag(0, 4);
             AP_SCHED_FENCE();
         }
-        if (PADGEN) load_frame(group, 1);
+        if (PADGEN) load_frame(gc, 1);
         transform(xkB, xmB, zhB, -1, 0, E2 ? raw2 : raw);
         // the next group's first frame lands under the store phase (during the second transform the
         // registers hold the first frame's spectrum instead)
         AP_SCHED_FENCE();
         if (GL) gl_load_mag(4, 8);
         // (GL: the projection's operands fill the registers until half of the chunks are out: the prefetch waits)
-        if (!GL && !PADGEN && !T2 && group + 1 < g_hi) load_frame(group + 1, 0);
+        if (!GL && !PADGEN && !T2 && group + 1 < g_hi) load_frame(gc_n, 0);
         AP_SCHED_FENCE();
         AP_PH(4);
 
@@ -294,10 +304,10 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             AP_LDS_BARRIER();                                            // the exchange buffers are the waves' again
             AP_PH(6);
             if (!PADGEN && group + 1 < g_hi) {                      // into an idle pipe, ahead of the stores
-                load_frame(group + 1, 0);
-                load_frame_to(raw2, group + 1, 1);
+                load_frame(gc_n, 0);
+                load_frame_to(raw2, gc_n, 1);
             }
-            issue_stores(group);
+            issue_stores(gc);
             AP_PH(7);
             continue;
         }
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             AP_PH(6);
             if (GL && c == 4) {
                 AP_SCHED_FENCE();
-                if (!PADGEN && group + 1 < g_hi) load_frame(group + 1, 0);
+                if (!PADGEN && group + 1 < g_hi) load_frame(gc_n, 0);
                 AP_SCHED_FENCE();
             }
             // thread (sq = tid / 16, sf = tid % 16) owns position sf of the windows of the chunk's rows
