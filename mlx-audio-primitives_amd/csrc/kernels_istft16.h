@@ -273,35 +273,40 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         const int64_t p0 = (int64_t)t0i * H;                         // padded position of r = 0
         float *yb = P.y + b * P.out_len;
         const int64_t n0 = p0 - P.out_offset;                        // output index of r = 0
-        for (int r = 4 * tid; r < n_own + CN; r += 4 * 64 * APS_WAVES) {
+        // A thread's positions r = 4 tid + 2048 k all lie in hop number rq = r >> hs = (wave >> (hs - 8)) + k (2048 >> hs),
+        // the same for the whole wave: which frames cover r, whether it has a carry in or out, whether it is emitted and
+        // which divisor applies are SCALAR decisions (spelled through rq so that the compiler makes them scalar branches
+        // instead of compares, masks and divergent loops in every lane)
+        constexpr int NQ = (2 * APW_NC) >> hs;                       // frames that cover a position (n_fft / hop)
+        for (int r = 4 * tid;; r += 4 * 64 * APS_WAVES) {
+            const int rq = AP_UNIFORM(r >> hs);
+            if (rq >= APS_WAVES - 1 + NQ) break;                     // r >= n_own + CN
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            if (r < CN) {
+            if (rq < NQ - 1) {                                       // r < CN
                 const ap_float4 c4 = *reinterpret_cast<const ap_float4 *>(carry_in + r);
                 s0 = c4.x; s1 = c4.y; s2 = c4.z; s3 = c4.w;
             }
-            // frames of this step that cover r: f H <= r < f H + n_fft (arithmetic shifts floor)
-            const int f_cov = ((r - 2 * APW_NC) >> hs) + 1;          // first covering frame, may be < 0
+            // frames of this step that cover r: f H <= r < f H + n_fft
+            const int f_cov = rq - NQ + 1;                           // first covering frame, may be < 0
             const int f_lo = f_cov < 0 ? 0 : f_cov;
-            int f_hi = r >> hs;
-            if (f_hi > APS_WAVES - 1) f_hi = APS_WAVES - 1;
+            const int f_hi = rq > APS_WAVES - 1 ? APS_WAVES - 1 : rq;
             for (int f = f_lo; f <= f_hi; ++f) {
                 const int sidx = r - (f << hs);                      // sample index in frame f (multiple of 4)
                 const ap_float4 q = *reinterpret_cast<const ap_float4 *>(
                     XF + f * (2 * APW_X_COMPLEX) + 2 * apw_zidx(sidx >> 1));
                 s0 += q.x; s1 += q.y; s2 += q.z; s3 += q.w;
             }
-            if (r >= n_own) {                                        // contributions to the next step's range
+            if (rq >= APS_WAVES) {                                   // r >= n_own: contributions to the next step's range
                 ap_float4 c4; c4.x = s0; c4.y = s1; c4.z = s2; c4.w = s3;
                 *reinterpret_cast<ap_float4 *>(carry_out + (r - n_own)) = c4;
             }
-            if (emit && (r < n_own || clip_last)) {
+            if (emit && (rq < APS_WAVES || clip_last)) {
                 // window-sum-of-squares over the frames of the CLIP that cover the position
                 // (relative frame numbers; frames before this step count too)
-                int F_lo = f_cov < -t0i ? -t0i : f_cov;
-                int F_hi = r >> hs;
-                if (F_hi > Ti - 1 - t0i) F_hi = Ti - 1 - t0i;
+                const int F_lo = f_cov < -t0i ? -t0i : f_cov;
+                const int F_hi = rq > Ti - 1 - t0i ? Ti - 1 - t0i : rq;
                 float w0, w1, w2, w3;                                // reciprocals of the divisors
-                if (F_lo == f_cov && F_hi == (r >> hs)) {            // every covering frame exists: by phase
+                if (F_lo == f_cov && F_hi == rq) {                   // every covering frame exists: by phase
                     const ap_float4 iv = *reinterpret_cast<const ap_float4 *>(INV + (r & (H - 1)));
                     w0 = iv.x; w1 = iv.y; w2 = iv.z; w3 = iv.w;
                 } else {                                             // the clip's first and last n_fft - hop positions
