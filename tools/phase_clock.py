@@ -24,7 +24,12 @@ g = torch.Generator(device="cuda").manual_seed(1)
 L = 220500
 ys = [torch.randn((256, L), device="cuda", generator=g) * 0.1 for _ in range(3)]
 stft_padded_rows = importlib.import_module("mlx_audio_primitives_amd.stft").stft_padded_rows
-if op == "istft":
+if op == "gl":                        # the STFT with the Griffin-Lim projection in its store phase (cfg3: 64 x 5 s)
+    Sm = [torch.rand((64, 1025, 216), device="cuda", generator=g) for _ in range(3)]
+    fn = lambda i: ap.griffinlim(Sm[i % 3], n_iter=4, hop_length=512, length=110250, random_state=0)
+    names = ["window", "load issue", "forward", "split", "prefetch", "store:lds write", "store:bar", "store:read+global", "-", "-", "-", "-"]
+    reader = ext.lib().ap_phase_read_stft16
+elif op == "istft":
     Ss = [stft_padded_rows(y, n_fft=2048, hop_length=512) for y in ys]
     fn = lambda i: ap.istft(Ss[i % 3], hop_length=512, length=L)
     names = ["stage:read", "merge", "forward", "window", "gather", "setup", "bar(half)", "bar(gather)", "stage:wait+write", "stage:bar", "stage:issue", "-"]
@@ -34,7 +39,7 @@ else:
     fn = lambda i: stft_padded_rows(ys[i % 3], n_fft=2048, hop_length=512, out=outs[i % 3])
     names = ["window", "load issue", "forward", "split", "prefetch", "store:lds write", "store:bar", "store:read+global", "-", "-", "-", "-"]
     reader = ext.lib().ap_phase_read_stft16
-for i in range(300):
+for i in range(300 if op != "gl" else 30):
     fn(i)
 torch.cuda.synchronize()
 buf = np.zeros(256 * 8 * 12, np.uint64)
