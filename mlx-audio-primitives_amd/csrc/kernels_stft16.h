@@ -27,8 +27,10 @@
 #include "kernels_pointwise.h"
 
 #ifdef AP_HOST_EMU
+struct ap_f4v { float x, y, z, w; };
 #define AP_STORE2(p, v, NT) (*(p) = (v))
 #else
+typedef float ap_f4v __attribute__((ext_vector_type(4)));        // two complex values as one 16-byte register quad
 #define AP_STORE2(p, v, NT)                                      \
     do {                                                         \
         if (NT) __builtin_nontemporal_store((v), (p));           \
@@ -218,6 +220,37 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         ap_float2 xkA[8], xmA[8], zhA, xkB[8], xmB[8], zhB;
         ap_float2 gpv[8][4], gpv_mid = ap_mk(0.0f, 0.0f);        // GL: previous raw spectrum of this thread's elements
         float gmg[8][4], gmg_mid = 0.0f;                          // GL: target magnitudes
+        // GL = 2: the store role is (row sq8 = tid / 8, frames 2 sp and 2 sp + 1, sp = tid % 8) of the chunk's rows sq8
+        // (bin 64 c + sq8) and 64 + sq8 (bin 1024 - 64 c - sq8): the same 33 elements per thread as 16-BYTE accesses to
+        // the three complex arrays.  The CU's vector-memory pipe charges per instruction (~18 cycles a store, ~12-16 a
+        // load whatever its width: tools/store_width_probe.hip, ta_probe.hip): 34 stores + 17 wide loads per thread and
+        // group instead of 66 + 33.  Measured: bit-identical and no faster (5.31-5.35 ms against 5.23-5.27 for 32
+        // iterations at cfg3) - the waves wait for the memory system behind the pipe, not for the pipe; AP_GL_PAIRS=1.
+        const int sq8 = tid >> 3, sp2 = 2 * (tid & 7);
+        ap_f4v gpw[8][2], gpw_mid = {0.0f, 0.0f, 0.0f, 0.0f};
+        float gmw[8][2][2], gmw_mid0 = 0.0f, gmw_mid1 = 0.0f;
+        const bool ok0 = sp2 < trem, ok1 = sp2 + 1 < trem;       // the thread's two frames exist
+        auto gl2_bin = [&](int c, int e, int q) __attribute__((always_inline)) { return e ? APW_NC - 64 * c - q : 64 * c + q; };
+        auto gl2_load_mag = [&](int c0, int c1) __attribute__((always_inline)) {
+            int q = sq8, f = sp2;
+            AP_PIN(q);
+            AP_PIN(f);
+            const float *mb = P.gl_mag + b * (int64_t)F * P.T + t0;
+            const int Td = (int)P.T;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c >= c0 && c < c1) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        gmw[c][e][0] = ok0 ? mb[gl2_bin(c, e, q) * Td + f] : 0.0f;
+                        gmw[c][e][1] = ok1 ? mb[gl2_bin(c, e, q) * Td + f + 1] : 0.0f;
+                    }
+                    if (c == 7 && tid < 8) {
+                        gmw_mid0 = ok0 ? mb[(APW_NC / 2) * Td + f] : 0.0f;
+                        gmw_mid1 = ok1 ? mb[(APW_NC / 2) * Td + f + 1] : 0.0f;
+                    }
+                }
+        };
         // the magnitudes of chunks c0 .. c1 - 1 (the first two ride with the previous spectrum before the
         // transforms, the rest are fetched when the transforms' registers are free again: 25 registers less at the peak)
         auto gl_load_mag = [&](int c0, int c1) {
@@ -239,7 +272,20 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                     if (c == 7 && tid < APS16_G) gmg_mid = ok ? mb[(APW_NC / 2) * Td + sf] : 0.0f;
                 }
         };
-        if (GL) {
+        if (GL == 2) {
+            // (rows are padded to whole lines: a pair whose second frame does not exist still reads inside its row)
+            int q = sq8, f = sp2;
+            AP_PIN(q);
+            AP_PIN(f);
+            const ap_float2 *pb = P.gl_prev + b * (int64_t)F * P.Ts + t0;
+            const ap_f4v zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    gpw[c][e] = ok0 ? *reinterpret_cast<const ap_f4v *>(&pb[gl2_bin(c, e, q) * Ts + f]) : zero4;
+            if (tid < 8) gpw_mid = ok0 ? *reinterpret_cast<const ap_f4v *>(&pb[(APW_NC / 2) * Ts + f]) : zero4;
+        } else if (GL) {
             int sq = sq0, sf = sf0;
             AP_PIN(sq);
             AP_PIN(sf);
@@ -259,7 +305,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         transform(xkA, xmA, zhA, E2 ? -1 : gc, 1, raw);
         if (GL) {                                  // the first four chunks' magnitudes land under the second transform
             AP_SCHED_FENCE();
-            gl_load_mag(0, 4);
+            if (GL == 2) gl2_load_mag(0, 4);
+            else gl_load_mag(0, 4);
             AP_SCHED_FENCE();
         }
         if (PADGEN) load_frame(gc, 1);
@@ -267,7 +314,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
         // the next group's first frame lands under the store phase (during the second transform the
         // registers hold the first frame's spectrum instead)
         AP_SCHED_FENCE();
-        if (GL) gl_load_mag(4, 8);
+        if (GL == 2) gl2_load_mag(4, 8);
+        else if (GL) gl_load_mag(4, 8);
         // (GL: the projection's operands fill the registers until half of the chunks are out: the prefetch waits)
         if (!GL && !PADGEN && !T2 && group + 1 < g_hi) load_frame(gc_n, 0);
         AP_SCHED_FENCE();
@@ -370,7 +418,48 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             }
             bins[4] = APW_NC / 2;
             slots[4] = 128;
-            if (ALIGNED) {
+            if constexpr (GL == 2) {
+                // two frames of two rows (+ bin 512 in the last chunk, threads 0..7) as 16-byte stores
+                int q = sq8, f = sp2;
+                AP_PIN(q);
+                AP_PIN(f);
+                const int ne2 = c == 7 ? 3 : 2;
+                ap_float2 x0[3], x1[3];
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (e < ne2) {
+                        const int slot = e == 2 ? 128 : e * 64 + q;
+                        x0[e] = buf[slot * APS16_OB_ROW + f];
+                        x1[e] = buf[slot * APS16_OB_ROW + f + 1];
+                    }
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (e < ne2) {
+                        const bool mine = e < 2 || tid < 8;
+                        const int bin = e == 2 ? APW_NC / 2 : gl2_bin(c, e, q);
+                        const float s0m = e == 2 ? gmw_mid0 : gmw[c][e == 2 ? 0 : e][0], s1m = e == 2 ? gmw_mid1 : gmw[c][e == 2 ? 0 : e][1];
+                        const ap_f4v pv = e == 2 ? gpw_mid : gpw[c][e == 2 ? 0 : e];
+                        // the arithmetic of ap_gl_rows_kernel (kernels_pointwise.h), operation for operation
+                        const ap_float2 u0 = ap_unit_phase(x0[e]), u1 = ap_unit_phase(x1[e]);
+                        ap_float2 r0 = ap_mk(s0m * u0.x, s0m * u0.y), r1 = ap_mk(s1m * u1.x, s1m * u1.y);
+                        if (P.gl_momentum > 0.0f) {
+                            const ap_float2 v0 = ap_unit_phase(ap_mk(pv.x, pv.y)), v1 = ap_unit_phase(ap_mk(pv.z, pv.w));
+                            r0 = ap_mk(r0.x + P.gl_momentum * (r0.x - s0m * v0.x), r0.y + P.gl_momentum * (r0.y - s0m * v0.y));
+                            r1 = ap_mk(r1.x + P.gl_momentum * (r1.x - s1m * v1.x), r1.y + P.gl_momentum * (r1.y - s1m * v1.y));
+                        }
+                        ap_float2 *po = &ob[bin * Ts + f];
+                        ap_float2 *pr = &P.gl_rebuilt[b * (int64_t)F * P.Ts + t0 + bin * Ts + f];
+                        if (mine && ok1) {
+                            const ap_f4v w4 = {x0[e].x, x0[e].y, x1[e].x, x1[e].y};
+                            const ap_f4v r4 = {r0.x, r0.y, r1.x, r1.y};
+                            *reinterpret_cast<ap_f4v *>(po) = w4;
+                            *reinterpret_cast<ap_f4v *>(pr) = r4;
+                        } else if (mine && ok0) {
+                            *po = x0[e];
+                            *pr = r0;
+                        }
+                    }
+            } else if (ALIGNED) {
                 ap_float2 x[5];
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
@@ -383,7 +472,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
                         if (P.stagger & 0x100) { if (x[i].x == 123.456f) ob[0] = x[i]; continue; }   // diagnostic knock-out: no stores
 #endif
                         if (mine && sf < trem) AP_STORE2(&ob[bins[i] * Ts + sf], x[i], NT);
-                        if (GL && mine && sf < trem) {
+                        if (GL == 1 && mine && sf < trem) {
                             // the arithmetic of ap_gl_rows_kernel (kernels_pointwise.h), operation for operation
                             const float sm = i < 4 ? gmg[c][i] : gmg_mid;
                             const ap_float2 u = ap_unit_phase(x[i]);

@@ -61,6 +61,10 @@ int ap_launch_stft16_gl(const ApStftParams &P, int64_t B, int64_t Ts, const floa
     W.gl_mag = mag;
     W.gl_rebuilt = reinterpret_cast<ap_float2 *>(rebuilt);
     W.gl_momentum = momentum;
+    // A/B switch: AP_GL_PAIRS=1 two frames per thread as 16-byte accesses (GL = 2): half the vector-memory instructions,
+    // bit-identical results, no faster (cfg3, 32 iterations, same box: 5.31-5.35 ms against 5.23-5.27; one stream 5.90 / 5.92)
+    static const bool pairs = std::getenv("AP_GL_PAIRS") && std::atoi(std::getenv("AP_GL_PAIRS")) != 0;
+    if (pairs) return ap_clip_loads_ok(W) ? ap_stft16_go<0, 1, 0, 2>(W, grid, stream) : ap_stft16_go<1, 1, 0, 2>(W, grid, stream);
     if (!ap_clip_loads_ok(W)) return ap_stft16_go<1, 1, 0, 1>(W, grid, stream);
     return ap_stft16_go<0, 1, 0, 1>(W, grid, stream);
 }

@@ -295,6 +295,40 @@ def istft_fused(S, hop, window, out_len, out_offset=None, grid_cap=0):
     return out
 
 
+def _aligned128(a):
+    """A copy of `a` whose data starts on a 128-byte boundary."""
+    raw = np.empty(a.nbytes + 128, np.uint8)
+    off = (-raw.ctypes.data) % 128
+    out = raw[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def stft16_gl(y, hop, window, prev, mag, momentum, center=True, pad_mode=0, Ts=None, grid_cap=2, variant=2):
+    """kernels_stft16.h with the Griffin-Lim projection in its store phase: returns (raw spectrum, rebuilt) as
+    (B, 1025, T) complex arrays; `prev` (B, 1025, T) complex, `mag` (B, 1025, T) float; rows held Ts apart."""
+    y = np.ascontiguousarray(y, np.float32)
+    B, L = y.shape
+    T = n_frames(L, 2048, hop, center)
+    Ts = -(-T // 16) * 16 if Ts is None else Ts
+
+    def padded(a, fill):
+        buf = np.full((B, 1025, Ts), fill, np.complex64)
+        if a is not None:
+            buf[:, :, :T] = a
+        return _aligned128(buf)
+
+    pv = padded(prev, np.complex64(3e3 - 2e3j))
+    out = padded(None, np.complex64(-777 - 777j))
+    reb = padded(None, np.complex64(-555 - 555j))
+    mag = np.ascontiguousarray(mag, np.float32)
+    window = np.ascontiguousarray(window, np.float32)
+    tw = twiddles(2048)
+    _check(lib().emu_stft16_gl_f32(_p(y), _i64(B), _i64(L), hop, _p(window), _p(tw), int(center), pad_mode, _i64(T), _i64(Ts),
+                                   _p(pv), _p(mag), ctypes.c_float(momentum), _p(out), _p(reb), grid_cap, variant))
+    return out[:, :, :T].copy(), reb[:, :, :T].copy(), out, reb
+
+
 def istft16(S, hop, window, out_len, out_offset=1024, grid_cap=0, Ts=None, variant=0):
     """kernels_istft16.h: fused ISTFT of an n_fft = 2048 (B, 1025, T) spectrum held with rows Ts apart."""
     S = np.ascontiguousarray(S, np.complex64)

@@ -192,6 +192,36 @@ int emu_stft16_f32(const float *y, int64_t B, int64_t L, int hop, const float *w
     return aligned;
 }
 
+// The STFT with the Griffin-Lim projection in its store phase (kernels_stft16.h, GL = 1: 8-byte accesses, GL = 2: two
+// frames per thread as 16-byte accesses): raw spectrum -> out, rebuilt = S unit(raw) + m (S unit(raw) - S unit(prev)),
+// all complex arrays with rows Ts apart, `mag` dense (B, 1025, T)
+int emu_stft16_gl_f32(const float *y, int64_t B, int64_t L, int hop, const float *window, const float *tw,
+                      int center, int pad_mode, int64_t T, int64_t Ts, const float *prev, const float *mag, float momentum,
+                      float *out, float *rebuilt, int grid_cap, int variant) {
+    ApStftParams P;
+    int rc = ap_prepare_stft(P, y, B, L, 2048, hop, window, tw, center, pad_mode, T);
+    if (rc != AP_OK) return rc;
+    P.out_c = reinterpret_cast<ap_float2 *>(out);
+    ApStft16Params W;
+    int grid = 0, aligned = 0;
+    if (ap_prepare_stft16(W, P, B, Ts, &grid, &aligned) != AP_OK || !aligned) return AP_ERR_UNSUPPORTED;
+    W.gl_prev = reinterpret_cast<const ap_float2 *>(prev);
+    W.gl_mag = mag;
+    W.gl_rebuilt = reinterpret_cast<ap_float2 *>(rebuilt);
+    W.gl_momentum = momentum;
+    if (grid > grid_cap) grid = grid_cap;
+    const bool pg = !ap_clip_loads_ok(W);
+    emu_lds_limit(W.lds_bytes);
+    if (variant == 2) {
+        if (pg) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<1, 1, 0, 2>(W); });
+        else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<0, 1, 0, 2>(W); });
+    } else {
+        if (pg) emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<1, 1, 0, 1>(W); });
+        else emu_launch((unsigned)grid, 64 * APS_WAVES, [&] { ap_stft2048_g16_kernel<0, 1, 0, 1>(W); });
+    }
+    return AP_OK;
+}
+
 int emu_melspec_f32(const float *y, int64_t B, int64_t L, int n_fft, int hop, const float *window,
                     const float *tw, int center, int pad_mode, int64_t T, const float *fb,
                     const int32_t *plan, const int32_t *desc, int n_mels, float power, float *out,

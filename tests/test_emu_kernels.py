@@ -95,6 +95,35 @@ def test_emu_stft16(hop, L, B, pad_mode, center, Ts, grid_cap, misalign, force_u
     assert np.all(raw[off:off + 2 * n].reshape(B, 1025, Tr, 2)[:, :, T:] == -777.0)
 
 
+@pytest.mark.parametrize("hop,L,B,momentum,grid_cap", [
+    (512, 10752, 3, 0.99, 2),       # T = 22: a full group and one with 6 frames per clip (odd pairs at the clip's end: T even)
+    (512, 11300, 2, 0.99, 1),       # T = 23: the last pair of every row has one frame
+    (512, 20000, 2, 0.0, 3),        # no momentum
+    (256, 9000, 1, 0.5, 2),
+])
+def test_emu_stft16_griffinlim_projection(hop, L, B, momentum, grid_cap):
+    """kernels_stft16.h, GL = 1 (8-byte accesses) and GL = 2 (two frames per thread, 16-byte accesses): raw spectrum and
+    rebuilt = S unit(raw) + m (S unit(raw) - S unit(prev)) (griffinlim.py:156-178), nothing written outside the T frames."""
+    rng = np.random.default_rng(hop + L)
+    y = rng.standard_normal((B, L)).astype(np.float32)
+    win = ao.padded_window("hann", 2048, 2048)
+    R = ao.stft(y, n_fft=2048, hop_length=hop)
+    T = R.shape[-1]
+    prev = (rng.standard_normal(R.shape) + 1j * rng.standard_normal(R.shape)).astype(np.complex64)
+    mag = rng.random(R.shape).astype(np.float32)
+    outs = {}
+    for variant in (1, 2):
+        raw, reb, raw_full, reb_full = eb.stft16_gl(y, hop, win, prev, mag, momentum, grid_cap=grid_cap, variant=variant)
+        np.testing.assert_allclose(raw, R, rtol=1e-4, atol=1e-4)
+        unit = lambda z: z / np.maximum(np.abs(z), 1e-30)
+        P = mag * unit(raw.astype(np.complex128))
+        want = P + momentum * (P - mag * unit(prev.astype(np.complex128)))
+        np.testing.assert_allclose(reb, want, rtol=2e-3, atol=2e-3)          # v_rsq_f32-grade reciprocal square roots
+        assert np.all(raw_full[:, :, T:] == np.complex64(-777 - 777j)) and np.all(reb_full[:, :, T:] == np.complex64(-555 - 555j))
+        outs[variant] = (raw, reb)
+    assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1], outs[2][1])      # bit for bit
+
+
 @pytest.mark.parametrize("sr,n_fft,hop,M,L,B,power", [
     (22050, 2048, 512, 128, 9000, 2, 2.0),
     (16000, 400, 160, 80, 5000, 3, 2.0),
