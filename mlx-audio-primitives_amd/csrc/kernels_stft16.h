@@ -184,6 +184,8 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_stft2048_g16_kernel(ApSt
             AP_SCHED_FENCE();
         }
         AP_PH(0);
+        // (requested here, behind the last store rounds' backlog, the loads block the wave for 3 500 - 6 000 cycles; requested
+        //  after the transform instead they do not land in time: 0.287-0.301 ms against 0.270-0.279, same box)
         if (!PADGEN && next_group >= 0) load_frame(next_group, next_second);   // lands under the transform
         AP_SCHED_FENCE();
         AP_PH(1);
