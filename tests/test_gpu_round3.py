@@ -449,12 +449,14 @@ def test_random_shapes_lines_vs_dense_vs_oracle():
         for S in (V, D, stft_mod.stft_padded_rows(yd, n_fft=2048, hop_length=hop, center=center, row_multiple=48)):
             yr = ap.istft(S, hop_length=hop, center=center, length=L)
             ref = ao.istft(R, hop_length=hop, n_fft=2048, center=center, length=L)
-            if center:
-                np.testing.assert_allclose(host(yr), ref, atol=2e-5, err_msg=tag)
-            else:                       # compare where the window sum is not tiny (see tests/test_emu_kernels.py)
-                wss = np.zeros(L + 4096)
-                w = ao.padded_window("hann", 2048, 2048).astype(np.float64) ** 2
-                for t in range(R.shape[-1]):
-                    wss[t * hop:t * hop + 2048] += w
-                ok = wss[:L] > 1e-2
-                np.testing.assert_allclose(host(yr)[:, ok], ref[:, ok], atol=2e-5, err_msg=tag)
+            # compare where the window sum of squares is not tiny (see tests/test_emu_kernels.py).  Centred too: with
+            # hop = 1024 the clip's last (L mod hop) + 1023 samples are covered by the last frame alone, and where its
+            # Hann value is ~1e-5 the division amplifies float32 rounding a thousandfold in the oracle and here alike
+            # (soak seed 7, trial 51: 3 of 2.7 M samples differed by 2.9e-5)
+            off = 1024 if center else 0
+            wss = np.zeros(L + 4096 + off)
+            w = ao.padded_window("hann", 2048, 2048).astype(np.float64) ** 2
+            for t in range(R.shape[-1]):
+                wss[t * hop:t * hop + 2048] += w
+            ok = wss[off:off + L] > 1e-2
+            np.testing.assert_allclose(host(yr)[:, ok], ref[:, ok], atol=2e-5, err_msg=tag)
