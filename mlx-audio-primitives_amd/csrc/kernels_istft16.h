@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         AP_PH(0);
         if (half) AP_LDS_BARRIER();
         AP_PH(6);
+        AP_PRIO(3);
         issue(0);
         ap_float2 v[16];
         ap_float2 tws0h = lc.tws0h;          // opaque per step: keeps the 8 merge twiddles out of loop-invariant registers
@@ -245,7 +246,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         AP_SCHED_FENCE();
         AP_PH(1);
         issue(1);
-        apw_forward<false, TIGHT>(v, X, TW1, lc);
+        apw_forward<false, TIGHT, true>(v, X, TW1, lc);
         AP_SCHED_FENCE();
         issue(2);
         AP_PH(2);
@@ -266,6 +267,7 @@ __global__ void __launch_bounds__(64 * APS_WAVES, 2) ap_istft2048_g16_kernel(ApI
         if (t0i == 0)                                                // a clip starts: nothing carried in
             for (int i = tid; i < CN; i += 64 * APS_WAVES) carry_in[i] = 0.0f;
         issue(3);
+        AP_PRIO(0);
         AP_PH(3);
         AP_LDS_BARRIER();
         AP_PH(7);

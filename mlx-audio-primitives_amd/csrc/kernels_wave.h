@@ -318,7 +318,18 @@ AP_DEV void apw_butterfly16_tight(ap_float2 (&v)[16]) {
     }
 }
 
-template <bool TO_LDS = true, bool TIGHT = false>
+// AP_PRIO(n): issue priority of the wave.  tools/phase_clock.py showed that of a SIMD's two waves the first gets the issue
+// slots and the second takes 1.4-1.6 x as long through the same transform, part of it alone on the SIMD with nothing to
+// cover its LDS waits.  A kernel that brackets its transform phase with AP_PRIO(3) ... AP_PRIO(0) and passes PRIO = true
+// lets a wave lower its priority as it advances, so the wave that is behind is served first (ISTFT: -1.2 ... -1.5 %,
+// same box; the STFT measured neutral and leaves it off).
+#ifndef AP_HOST_EMU
+#define AP_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define AP_PRIO(n) do {} while (0)
+#endif
+
+template <bool TO_LDS = true, bool TIGHT = false, bool PRIO = false>
 AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, const ApwLane &c) {
     const int lane = c.lane;
     if (TIGHT) {                                                   // twiddles fetched after the butterfly
@@ -340,6 +351,7 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = ap_mul_fw(v[k], t1[k]);
     }
+    if (PRIO) AP_PRIO(2);
     {   // transpose #1: (n0 = a + 4b, k1) -> lane (k1, a), register b
         const int a = lane & 3, bq = lane >> 2;
 #pragma unroll
@@ -374,6 +386,7 @@ AP_DEV void apw_forward(ap_float2 (&v)[16], ap_float2 *X, const ap_float2 *TW1, 
         for (int cc = 1; cc < 16; ++cc) v[cc] = ap_mul_fw(v[cc], t2[cc]);  // the table carries the signs s1 s2
     }
     // radix-4 across the quad (DIF) on v_fmac_f32_dpp, outputs in bit-reversed lanes
+    if (PRIO) AP_PRIO(1);
     apm_quad_radix4(v, m);
     // transpose #2: natural order Z[k], k = k1 + 16 c + 256 d (skipped when the caller stores
     // v[cc] = Z[k1p + 16 cc + 256 qd] itself)
