@@ -230,8 +230,10 @@ int ap_istft_f32(const float *S /*dev (B,F,T,2)*/, int64_t B, int64_t T, int n_f
                  void *stream);
 
 /* The same from a spectrum whose rows are `row_stride` complex values apart (the layout ap_stft_rows_f32
- * writes; row_stride == T is the dense layout).  n_fft = 2048 with hop in {256, 512, 1024} only (the fused
- * kernel: no workspace); AP_ERR_UNSUPPORTED otherwise - copy to a dense array and call ap_istft_f32. */
+ * writes; row_stride == T is the dense layout).  n_fft = 2048 with hop in {256, 512, 1024} and row_stride <= 490 000
+ * (a clip is addressed as one buffer resource: 1025 row_stride 8 bytes < 0xF0000000), and the eight-frame sizes
+ * (n_fft 512 / 400 / 256) only - the fused kernels, no workspace; AP_ERR_UNSUPPORTED otherwise - copy to a dense
+ * array and call ap_istft_f32. */
 int ap_istft_rows_f32(const float *S /*dev (B,F,row_stride,2)*/, int64_t B, int64_t T, int64_t row_stride,
                       int n_fft, int hop, const float *window /*dev*/, const float *tw /*dev*/,
                       int64_t out_offset, int64_t out_len, float *out /*dev (B,out_len)*/, void *stream);
